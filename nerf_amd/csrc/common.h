@@ -1,0 +1,71 @@
+// common.h -- shared declarations of libnerfhip (host + device).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nerfhip.h"
+
+namespace nh {
+
+constexpr int kMaxD = NERFHIP_MAX_D;
+constexpr int kEncPad = 64;      // positional encoding rows, zero padded (posL <= 10 -> E <= 63)
+constexpr int kTile = 128;       // samples per workgroup of the fused MLP kernels (4 waves x 32)
+constexpr int kMaxChunks = 192;  // weight chunks of one network's forward stream
+
+// Canonical flat layout of ONE network's parameters (DJL child order).  Offsets in floats.
+struct NetLayout {
+  int D, W, E, Ed, H2;
+  int mode;              // 0: Linear(3) | 1: view-dir head | 2: SH head  (nerfCoreBlock.scala:52-83)
+  int head_rows;         // rows of the first head matrix: H2 | 27 | 3
+  int fan_in[kMaxD];
+  uint32_t skip_mask;    // bit l set: output of layer l is concatenated with the encoding
+  int64_t w_off[kMaxD], b_off[kMaxD];
+  int64_t ws_off, bs_off;
+  int64_t wf_off, bf_off;   // first head matrix [head_rows][W] and its bias
+  int64_t wd_off, bd_off;   // mode 1: [H2][Ed]
+  int64_t wc_off, bc_off;   // mode 1: [3][H2]
+  int64_t count;
+};
+
+// One weight chunk of a packed stream: 32 k-values x R rows.
+struct ChunkDesc {
+  int64_t src_off;     // float offset of the matrix in the canonical network parameters
+  int32_t ld;          // row length (fan_in) of the canonical matrix
+  int32_t transposed;  // 0: A[i][k] = src[i*ld + c0 + k]   1: A[i][k] = src[(c0 + k)*ld + i]
+  int32_t c0;          // first canonical column (or row, when transposed) of this chunk; -1 = all zero
+  int32_t kvalid;      // k < kvalid are real, the rest zero padding
+  int32_t ivalid;      // i < ivalid are real rows
+  int32_t R;           // rows in the chunk (multiple of 32)
+  uint32_t dst_off;    // float offset in the packed stream
+  uint32_t pad;
+};
+
+// Kernel-side description of one network (passed by value).
+struct NetArgs {
+  const float* params;         // canonical fp32 parameters of this network
+  const float* vecpack;        // 16-byte aligned copies of the small vectors (see pack.hip):
+                               //   [l*W] b_l | [D*W] w_sigma | [(D+1)*W] head bias (zero padded to HT*32)
+                               //   [(D+2)*W] wc [3][HT*32] zero padded | [(D+5)*W] b_sigma, bc[0..2]
+  const void* wpack_fwd;       // packed forward stream (fp32 or bf16)
+  const void* wpack_bwd;       // packed backward (transposed) stream
+  const uint32_t* off_fwd;     // [n_fwd+1] element offsets of the forward chunks
+  const uint32_t* off_bwd;     // [n_bwd+1]
+  int32_t n_fwd, n_fwd_trunk, n_bwd;   // n_fwd_trunk: chunks up to and excluding the colour head
+  int32_t D, W, E, mode, HT, head_rows, H2;
+  uint32_t skip_mask;
+};
+
+inline int64_t vecpack_floats(int D, int W) { return (int64_t)(D + 5) * W + 4; }
+
+// activation store of one training pass over M samples (feature-major: [row][Mpad]), fp32
+struct ActStore {
+  float* enc;    // [64][Mpad]
+  float* act;    // [D][W][Mpad]   post-ReLU outputs of the trunk layers
+  float* hc;     // [HT*32][Mpad]  mode 1: post-ReLU colour hidden layer
+  float* dy;     // [D][W][Mpad]   gradients w.r.t. the pre-activations (written by backward)
+  float* dh;     // [HT*32 + 32][Mpad] head gradients: rows < HT*32 d(head pre-act), row HT*32 = d sigma,
+                 //                    rows HT*32+1..+3 = d craw^T (mode 1)
+  int64_t Mpad;
+};
+
+}  // namespace nh

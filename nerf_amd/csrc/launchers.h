@@ -1,0 +1,40 @@
+// launchers.h -- host-callable launch functions of the HIP kernels (defined in the .hip files).
+#pragma once
+#include "common.h"
+
+namespace nh {
+
+// ray_kernels.hip
+hipError_t launch_stratified(const float* bounds, const float* t_rand, int64_t n, int N, int lin_disp, int perturb,
+                             uint64_t seed, uint32_t step, float* z, hipStream_t s);
+hipError_t launch_composite_fwd(const float* sigma, const float* noise, const float* craw, const float* z, int64_t n,
+                                int S, float noise_std, int white, uint64_t seed, uint32_t step, uint32_t stream,
+                                float* w, float* rgb, float* depth, float* acc, hipStream_t s);
+hipError_t launch_composite_bwd(const float* sigma, const float* noise, const float* craw, const float* z,
+                                const float* d_rgb, int64_t n, int S, float noise_std, int white, uint64_t seed,
+                                uint32_t step, uint32_t stream, float* d_sigma, float* d_craw, hipStream_t s);
+hipError_t launch_sample_pdf(const float* w, const float* z, const float* u_rand, int64_t n, int N, int NI, int perturb,
+                             uint64_t seed, uint32_t step, float* cdf, int32_t* ind, float* zs, float* z_fine,
+                             hipStream_t s);
+hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float near, float far, int use_ndc,
+                           float* rays_o, float* rays_d, float* bounds, hipStream_t s);
+hipError_t launch_to_u8(const float* rgb, int64_t n, uint8_t* out, hipStream_t s);
+
+// pack.hip
+hipError_t launch_pack_chunks(const float* params, const ChunkDesc* descs, int n, float* dst, hipStream_t s);
+hipError_t launch_pack_vec(const float* params, const NetLayout& L, int HT, float* vp, hipStream_t s);
+hipError_t launch_dir_branch(const float* params, const NetLayout& L, int Rh, const float* viewdir, int64_t n,
+                             float* dirvec, float* encT, int64_t Bpad, hipStream_t s);
+hipError_t launch_sh2(const float* viewdir, int64_t n, float* Y, hipStream_t s);
+hipError_t launch_l2_loss(const float* pred, const float* label, int64_t n3, double* loss_acc, float* d_rgb,
+                          hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lrp, float grad_scale,
+                       hipStream_t s);
+hipError_t launch_init(float* p, int64_t off, int64_t n, float sd, uint64_t seed, hipStream_t s);
+
+// mlp_fwd.hip
+hipError_t launch_mlp_fwd_f32(bool train, const NetArgs& net, const float* rays_o, const float* rays_d, const float* z,
+                              const float* dirfeat, int64_t M, int S, float* sigma, float* craw, int want_rgb,
+                              const ActStore& st, hipStream_t stream);
+
+}  // namespace nh

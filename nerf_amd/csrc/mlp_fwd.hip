@@ -1,0 +1,202 @@
+// mlp_fwd.hip -- fused positional-encoding + density/colour MLP forward on fp32 MFMA (gfx950).
+//
+// Computes nerfCoreBlock.forwardInternal (reference nerf/nerfCoreBlock.scala:107-112) for a flat list of
+// samples m = ray*S + i: position o + d*z (nerfBlock.scala:65), positionCode (:127-136) generated in
+// registers as the B operand of layer 0 (and of the layer after a skip), D x (Linear+ReLU) with the
+// skip concat (:19-32), density head (:34-44), colour head view-dir / SH / plain (:50-85).
+// No activation ever leaves the CU in inference; the training variant also stores the post-ReLU
+// activations feature-major for the backward pass.
+//
+// Work decomposition: one workgroup = 4 waves = 128 samples; one wave = 32 samples x all features;
+// 1 wave per SIMD with the 512-register file (accumulators 128 + previous layer 128 + encoding 32).
+// Weights stream through LDS in chunks of 32 input features (see mlp_common.cuh), double buffered with
+// global_load_lds (LDS-DMA).
+#include "mlp_common.cuh"
+
+namespace nh {
+
+template <int WT, bool TRAIN>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const float* __restrict__ rays_o,
+                                                             const float* __restrict__ rays_d,
+                                                             const float* __restrict__ z,
+                                                             const float* __restrict__ dirfeat, int64_t M, int S,
+                                                             float* __restrict__ sigma, float* __restrict__ craw,
+                                                             int want_rgb, ActStore st) {
+  constexpr int R = 32 * WT;
+  constexpr int HTM = WT >= 2 ? WT / 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[2][32 * R];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int64_t m = (int64_t)blockIdx.x * kTile + wave * 32 + li;
+  const bool valid = m < M;
+  const int64_t mc = valid ? m : M - 1;
+  const int64_t ray = mc / S;
+  const float* vp = net.vecpack;
+  const int W = net.W, D = net.D;
+
+  ChunkPipe pipe;
+  pipe.wpack = (const float*)net.wpack_fwd;
+  pipe.off = net.off_fwd;
+  pipe.buf0 = lds[0];
+  pipe.buf1 = lds[1];
+  pipe.n = want_rgb ? net.n_fwd : net.n_fwd_trunk;
+  pipe.wave = wave;
+  pipe.lane = lane;
+  pipe.prime();
+
+  // sample position (raysO.add(raysD.mul(zVals)), nerfBlock.scala:65): separate mul and add
+  const float zz = z[mc];
+  const float px = __fadd_rn(rays_o[ray * 3 + 0], __fmul_rn(rays_d[ray * 3 + 0], zz));
+  const float py = __fadd_rn(rays_o[ray * 3 + 1], __fmul_rn(rays_d[ray * 3 + 1], zz));
+  const float pz = __fadd_rn(rays_o[ray * 3 + 2], __fmul_rn(rays_d[ray * 3 + 2], zz));
+
+  f32x16 enc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) enc[t][r] = code_value(px, py, pz, tile_row(t, r, h), net.E);
+  if (TRAIN) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st.enc[(int64_t)tile_row(t, r, h) * st.Mpad + m] = valid ? enc[t][r] : 0.f;
+  }
+
+  f32x16 act[WT], acc[WT];
+  for (int l = 0; l < D; ++l) {
+    load_rows<WT>(acc, vp + l * W, WT, W, h);  // accumulator := bias
+    if (l > 0) {
+#pragma unroll
+      for (int kt = 0; kt < WT; ++kt) mm_chunk<WT>(acc, act[kt], pipe.next(), R, WT, li, h);
+    }
+    if (l == 0 || ((net.skip_mask >> (l - 1)) & 1u)) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) mm_chunk<WT>(acc, enc[kt], pipe.next(), R, WT, li, h);
+    }
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) act[t][r] = fmaxf(acc[t][r], 0.f);
+    if (TRAIN) {
+      float* dst = st.act + (int64_t)l * W * st.Mpad + m;
+#pragma unroll
+      for (int t = 0; t < WT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(int64_t)tile_row(t, r, h) * st.Mpad] = valid ? act[t][r] : 0.f;
+    }
+  }
+
+  // density head (nerfCoreBlock.scala:39-40): dot over this lane's half of the features + the other half
+  {
+    const float* ws = vp + D * W;
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + 32 * t + 8 * q + 4 * h);
+        part = fmaf(act[t][4 * q + 0], wv[0], part);
+        part = fmaf(act[t][4 * q + 1], wv[1], part);
+        part = fmaf(act[t][4 * q + 2], wv[2], part);
+        part = fmaf(act[t][4 * q + 3], wv[3], part);
+      }
+    part += __shfl_xor(part, 32);
+    if (valid && h == 0) sigma[m] = part + vp[(D + 5) * W];
+  }
+  if (!want_rgb) return;
+
+  // colour head (nerfCoreBlock.scala:50-89)
+  const int HT = net.HT;
+  const int Rh = 32 * HT;
+  f32x16 hacc[HTM];
+  if (net.mode == 1) load_rows<HTM>(hacc, dirfeat + ray * Rh, HT, Rh, h);   // Wd.enc(dir) + bd + bf, per ray
+  else load_rows<HTM>(hacc, vp + (D + 1) * W, HT, Rh, h);                   // head bias (zero padded)
+#pragma unroll
+  for (int kt = 0; kt < WT; ++kt) mm_chunk<HTM>(hacc, act[kt], pipe.next(), Rh, HT, li, h);
+
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  if (net.mode == 1) {
+    const float* wc = vp + (D + 2) * W;  // [3][Rh] zero padded
+#pragma unroll
+    for (int t = 0; t < HTM; ++t) {
+      if (t < HT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[t][r] = fmaxf(hacc[t][r], 0.f);  // add().relu() (:67)
+        if (TRAIN) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st.hc[(int64_t)tile_row(t, r, h) * st.Mpad + m] = valid ? hacc[t][r] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 32 * t + 8 * q + 4 * h;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wc + row);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(wc + Rh + row);
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(wc + 2 * Rh + row);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c0 = fmaf(hacc[t][4 * q + j], w0[j], c0);
+            c1 = fmaf(hacc[t][4 * q + j], w1[j], c1);
+            c2 = fmaf(hacc[t][4 * q + j], w2[j], c2);
+          }
+        }
+      }
+    }
+    if (h == 0) {
+      c0 += vp[(D + 5) * W + 1];
+      c1 += vp[(D + 5) * W + 2];
+      c2 += vp[(D + 5) * W + 3];
+    }
+  } else if (net.mode == 2) {
+    // reshape(...,9,3).mul(SH).sum(-2)  (:55): c[k] = sum_j q[3j+k] * Y_j(dir)
+    const float* Y = dirfeat + ray * 12;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tile_row(0, r, h);
+      if (row < 27) {
+        const int j = row / 3, k = row - 3 * j;
+        const float v = hacc[0][r] * Y[j];
+        c0 += k == 0 ? v : 0.f;
+        c1 += k == 1 ? v : 0.f;
+        c2 += k == 2 ? v : 0.f;
+      }
+    }
+  } else {
+    if (h == 0) { c0 = hacc[0][0]; c1 = hacc[0][1]; c2 = hacc[0][2]; }
+  }
+  c0 += __shfl_xor(c0, 32);
+  c1 += __shfl_xor(c1, 32);
+  c2 += __shfl_xor(c2, 32);
+  if (valid && h == 0) {
+    craw[m * 3 + 0] = c0;
+    craw[m * 3 + 1] = c1;
+    craw[m * 3 + 2] = c2;
+  }
+}
+
+template <int WT>
+static hipError_t launch_wt(bool train, const NetArgs& net, const float* rays_o, const float* rays_d, const float* z,
+                            const float* dirfeat, int64_t M, int S, float* sigma, float* craw, int want_rgb,
+                            const ActStore& st, hipStream_t stream) {
+  const dim3 grid((unsigned)((M + kTile - 1) / kTile)), block(256);
+  if (train)
+    hipLaunchKernelGGL((mlp_fwd_f32_kernel<WT, true>), grid, block, 0, stream, net, rays_o, rays_d, z, dirfeat, M, S,
+                       sigma, craw, want_rgb, st);
+  else
+    hipLaunchKernelGGL((mlp_fwd_f32_kernel<WT, false>), grid, block, 0, stream, net, rays_o, rays_d, z, dirfeat, M, S,
+                       sigma, craw, want_rgb, st);
+  return hipGetLastError();
+}
+
+hipError_t launch_mlp_fwd_f32(bool train, const NetArgs& net, const float* rays_o, const float* rays_d, const float* z,
+                              const float* dirfeat, int64_t M, int S, float* sigma, float* craw, int want_rgb,
+                              const ActStore& st, hipStream_t stream) {
+  switch (net.W / 32) {
+    case 1: return launch_wt<1>(train, net, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, st, stream);
+    case 2: return launch_wt<2>(train, net, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, st, stream);
+    case 4: return launch_wt<4>(train, net, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, st, stream);
+    case 8: return launch_wt<8>(train, net, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, st, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace nh

@@ -1,0 +1,441 @@
+// ray_kernels.hip -- the HBM-bound per-ray kernels of the hot path (gfx950, wave64):
+//   stratified sampling      nerfBlock.getSample/givePerturb/getInput (nerfBlock.scala:47-69)
+//   alpha compositing fwd    nerfBlock.getWeight + weighted sum + addBkgd (nerfBlock.scala:24-45,115)
+//   alpha compositing bwd    reverse mode of the same
+//   inverse-CDF resampling   nerfBlock.samplePdf (nerfBlock.scala:71-106)
+//   ray generation / u8      getDataSet.getRaysNp (+ndc), runNerf.renderToImage's uint8 cast
+// Layout is ray-major [ray][sample]; one WAVE owns one ray and walks its samples 64 at a time, so every
+// load/store is a contiguous 256-byte (768 for rgb) segment and the cumulative sums are wave-level
+// prefix scans with a carry between 64-sample chunks.
+//
+// Exactness notes: the CDF scan runs in fp64.  The reference's cumsum (libtorch CPU)
+// accumulates serially in double and rounds each element to fp32; the terms w+1e-5 lie in [2^-17, 2) so
+// every partial sum of <= 4096 of them is exactly representable in double (47 significant bits needed),
+// hence ANY summation order -- including this parallel scan -- yields bit-identical fp32 CDF entries
+// and therefore bit-identical bin indices.
+#include "common.h"
+#include "rng.cuh"
+
+namespace nh {
+
+// ---------------------------------------------------------------------------------------------
+// wave-level helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+// torch.linspace(0,1,n)[i] (fp32 step; second half evaluated with one rounding)
+__device__ __forceinline__ float linspace01(int i, int n) {
+  if (n == 1) return 0.f;
+  const float step = __fdiv_rn(1.0f, (float)(n - 1));
+  return (i < n / 2) ? __fmul_rn(step, (float)i) : fmaf(-step, (float)(n - i - 1), 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stratified sampling: z[ray][i]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float strat_z(float near, float far, int i, int N, int lin_disp) {
+  const float t = linspace01(i, N);
+  const float omt = -(__fsub_rn(t, 1.0f));
+  if (lin_disp)
+    return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(__fdiv_rn(1.0f, near), omt), __fmul_rn(__fdiv_rn(1.0f, far), t)));
+  return __fadd_rn(__fmul_rn(near, omt), __fmul_rn(far, t));
+}
+
+__global__ void stratified_kernel(const float* __restrict__ bounds, const float* __restrict__ t_rand, int64_t n, int N,
+                                  int lin_disp, int perturb, uint64_t seed, uint32_t step, float* __restrict__ z) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * N) return;
+  const int64_t ray = idx / N;
+  const int i = (int)(idx - ray * N);
+  const float near = bounds[ray * 2], far = bounds[ray * 2 + 1];
+  float zi = strat_z(near, far, i, N, lin_disp);
+  if (perturb) {  // givePerturb (nerfBlock.scala:50-57)
+    const float zl = i > 0 ? strat_z(near, far, i - 1, N, lin_disp) : zi;
+    const float zu = i < N - 1 ? strat_z(near, far, i + 1, N, lin_disp) : zi;
+    const float lower = i > 0 ? __fmul_rn(__fadd_rn(zi, zl), 0.5f) : zi;
+    const float upper = i < N - 1 ? __fmul_rn(__fadd_rn(zu, zi), 0.5f) : zi;
+    const float r = t_rand ? t_rand[idx] : philox_uniform(seed, kStreamPerturb, step, (uint64_t)idx);
+    zi = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), r));
+  }
+  z[idx] = zi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// compositing forward: one wave per ray
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ sigma,
+                                                            const float* __restrict__ noise,
+                                                            const float* __restrict__ craw, const float* __restrict__ z,
+                                                            int64_t n, int S, float noise_std, int white,
+                                                            uint64_t seed, uint32_t step, uint32_t stream,
+                                                            float* __restrict__ w, float* __restrict__ rgb,
+                                                            float* __restrict__ depth, float* __restrict__ acc) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n) return;
+  const float* sg = sigma + ray * S;
+  const float* zr = z + ray * S;
+  double carry = 0.0;     // cumSum(0) carried between chunks (double accumulator, as libtorch CPU)
+  float Tcarry = 1.0f;    // T of the last sample of the previous chunk
+  float sw = 0.f, sz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    float a = 0.f, zi = 0.f;
+    if (i < S) zi = zr[i];
+    if (i < S - 1) {
+      const float dist = __fsub_rn(zr[i + 1], zi);
+      float s = sg[i];
+      if (noise_std > 0.f) {  // addNoise (nerfBlock.scala:21)
+        const float nz = noise ? noise[ray * S + i] : philox_normal(seed, stream, step, (uint64_t)(ray * S + i));
+        s = __fadd_rn(s, __fmul_rn(nz, noise_std));
+      }
+      a = __fmul_rn(-fmaxf(s, 0.f), dist);
+    }
+    const double run = carry + wave_incl_scan((double)a, lane);
+    const float T = expf((float)run);
+    const float alpha = -(__fsub_rn(expf(a), 1.0f));
+    float Tprev = __shfl_up(T, 1);
+    if (lane == 0) Tprev = Tcarry;
+    float wi = 0.f;
+    if (i < S) wi = (i == 0) ? alpha : ((i < S - 1) ? __fmul_rn(Tprev, alpha) : Tprev);
+    carry = __shfl(run, 63);
+    Tcarry = __shfl(T, 63);
+    if (i < S) {
+      if (w) w[ray * S + i] = wi;
+      sw += wi;
+      sz = __fadd_rn(sz, __fmul_rn(wi, zi));
+      if (craw) {
+        const float* c = craw + (ray * S + i) * 3;
+        c0 = __fadd_rn(c0, __fmul_rn(wi, sigmoidf_(c[0])));
+        c1 = __fadd_rn(c1, __fmul_rn(wi, sigmoidf_(c[1])));
+        c2 = __fadd_rn(c2, __fmul_rn(wi, sigmoidf_(c[2])));
+      }
+    }
+  }
+  sw = wave_sum(sw); sz = wave_sum(sz);
+  c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+  if (lane == 0) {
+    if (rgb && craw) {
+      const float bk = white ? -(__fsub_rn(sw, 1.0f)) : 0.f;  // addBkgd (nerfBlock.scala:24-29)
+      rgb[ray * 3 + 0] = c0 + bk;
+      rgb[ray * 3 + 1] = c1 + bk;
+      rgb[ray * 3 + 2] = c2 + bk;
+    }
+    if (depth) depth[ray] = sz;
+    if (acc) acc[ray] = sw;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compositing backward: one wave per ray; forward scan (T) then reverse scan (suffix of dT*T).
+// dynamic LDS: 4 waves x 3 x Spad floats  (T, e=exp(a), dw)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ sigma,
+                                                            const float* __restrict__ noise,
+                                                            const float* __restrict__ craw, const float* __restrict__ z,
+                                                            const float* __restrict__ d_rgb, int64_t n, int S, int Spad,
+                                                            float noise_std, int white, uint64_t seed, uint32_t step,
+                                                            uint32_t stream, float* __restrict__ d_sigma,
+                                                            float* __restrict__ d_craw) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray_raw = (int64_t)blockIdx.x * 4 + wv;
+  const bool live = ray_raw < n;
+  const int64_t ray = live ? ray_raw : n - 1;
+  float* Ts = smem + (size_t)wv * 3 * Spad;
+  float* es = Ts + Spad;
+  float* dws = es + Spad;
+  const float* sg = sigma + ray * S;
+  const float* zr = z + ray * S;
+  const float g0 = d_rgb[ray * 3], g1 = d_rgb[ray * 3 + 1], g2 = d_rgb[ray * 3 + 2];
+  const float gsum = g0 + g1 + g2;
+  // pass 1 (forward): w, T, e, dw, d_craw
+  double carry = 0.0;
+  float Tcarry = 1.0f;
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    float a = 0.f, zi = 0.f;
+    if (i < S) zi = zr[i];
+    if (i < S - 1) {
+      const float dist = __fsub_rn(zr[i + 1], zi);
+      float s = sg[i];
+      if (noise_std > 0.f) {
+        const float nz = noise ? noise[ray * S + i] : philox_normal(seed, stream, step, (uint64_t)(ray * S + i));
+        s = __fadd_rn(s, __fmul_rn(nz, noise_std));
+      }
+      a = __fmul_rn(-fmaxf(s, 0.f), dist);
+    }
+    const double run = carry + wave_incl_scan((double)a, lane);
+    const float T = expf((float)run);
+    const float e = expf(a);
+    const float alpha = -(__fsub_rn(e, 1.0f));
+    float Tprev = __shfl_up(T, 1);
+    if (lane == 0) Tprev = Tcarry;
+    carry = __shfl(run, 63);
+    Tcarry = __shfl(T, 63);
+    if (i < S) {
+      const float wi = (i == 0) ? alpha : ((i < S - 1) ? __fmul_rn(Tprev, alpha) : Tprev);
+      const float* c = craw + (ray * S + i) * 3;
+      const float s0 = sigmoidf_(c[0]), s1 = sigmoidf_(c[1]), s2 = sigmoidf_(c[2]);
+      if (live) {
+        float* dc = d_craw + (ray * S + i) * 3;
+        dc[0] = wi * g0 * s0 * (1.0f - s0);
+        dc[1] = wi * g1 * s1 * (1.0f - s1);
+        dc[2] = wi * g2 * s2 * (1.0f - s2);
+      }
+      const float g = g0 * s0 + g1 * s1 + g2 * s2;
+      Ts[i] = T;
+      es[i] = e;
+      dws[i] = white ? g - gsum : g;
+    }
+  }
+  __syncthreads();
+  // pass 2 (reverse): da_j = sum_{i>=j} dT_i T_i - dalpha_j e_j ;  d sigma_j = (s_j > 0) ? -dist_j da_j : 0
+  double rcarry = 0.0;
+  const int nchunks = (S + 63) / 64;
+  for (int cidx = nchunks - 1; cidx >= 0; --cidx) {
+    const int j = cidx * 64 + (63 - lane);  // lane 0 takes the LAST sample of the chunk: forward scan == suffix sum
+    double term = 0.0;
+    if (j < S - 1) {
+      const float dT = (j == S - 2) ? dws[S - 1] : dws[j + 1] * (1.0f - es[j + 1]);
+      term = (double)dT * (double)Ts[j];
+    }
+    const double suf = rcarry + wave_incl_scan(term, lane);
+    rcarry = __shfl(suf, 63);
+    if (j < S - 1) {
+      const float dalpha = dws[j] * (j == 0 ? 1.0f : Ts[j - 1]);
+      const float da = (float)suf + dalpha * (-es[j]);
+      const float dist = __fsub_rn(zr[j + 1], zr[j]);
+      float s = sg[j];
+      if (noise_std > 0.f) {
+        const float nz = noise ? noise[ray * S + j] : philox_normal(seed, stream, step, (uint64_t)(ray * S + j));
+        s = __fadd_rn(s, __fmul_rn(nz, noise_std));
+      }
+      if (live) d_sigma[ray * S + j] = s > 0.f ? (-dist) * da : 0.f;
+    } else if (j == S - 1 && live) {
+      d_sigma[ray * S + j] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hierarchical inverse-CDF resampling: one wave per ray, CDF and bins staged in LDS
+// dynamic LDS per wave: cdf[Npad] + bins[Npad] + sortbuf[P] + ubuf[PU]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bitonic_sort_lds(float* a, int P, int lane) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < P; i += 64) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float x = a[i], y = a[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ w, const float* __restrict__ z,
+                                                         const float* __restrict__ u_rand, int64_t n, int N, int NI,
+                                                         int Npad, int P, int PU, int perturb, uint64_t seed,
+                                                         uint32_t step, float* __restrict__ cdf_out,
+                                                         int32_t* __restrict__ ind_out, float* __restrict__ zs_out,
+                                                         float* __restrict__ z_fine) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray_raw = (int64_t)blockIdx.x * 4 + wv;
+  const bool live = ray_raw < n;
+  const int64_t ray = live ? ray_raw : n - 1;
+  float* cdf = smem + (size_t)wv * (2 * Npad + P + PU);
+  float* bins = cdf + Npad;
+  float* sb = bins + Npad;
+  float* ub = sb + P;
+  const float* wr = w + ray * N;
+  const float* zr = z + ray * N;
+  const int nb = N - 1;
+  // weightCum = cumsum(weight[1:-1] + 1e-5)  (nerfBlock.scala:81): fp64 scan, each element rounded to fp32
+  double carry = 0.0;
+  for (int base = 0; base < N - 2; base += 64) {
+    const int k = base + lane;
+    const double t = (k < N - 2) ? (double)__fadd_rn(wr[k + 1], 1e-5f) : 0.0;
+    const double run = carry + wave_incl_scan(t, lane);
+    carry = __shfl(run, 63);
+    if (k < N - 2) cdf[k + 1] = (float)run;
+  }
+  for (int k = lane; k < nb; k += 64) bins[k] = __fmul_rn(__fadd_rn(zr[k + 1], zr[k]), 0.5f);
+  if (perturb) {  // randomUniform(...).sort(0)  (nerfBlock.scala:71)
+    for (int m = lane; m < PU; m += 64)
+      ub[m] = m < NI ? (u_rand ? u_rand[ray * NI + m] : philox_uniform(seed, kStreamPdf, step, (uint64_t)(ray * NI + m)))
+                     : __builtin_inff();
+  }
+  __syncthreads();
+  const float sum = cdf[N - 2];
+  __syncthreads();
+  for (int k = lane; k < nb; k += 64) cdf[k] = (k == 0) ? 0.f : __fdiv_rn(cdf[k], sum);  // cdf = [0, wc/sum]
+  if (perturb) bitonic_sort_lds(ub, PU, lane);
+  __syncthreads();
+  if (cdf_out && live)
+    for (int k = lane; k < nb; k += 64) cdf_out[ray * nb + k] = cdf[k];
+  for (int m = lane; m < NI; m += 64) {
+    const float u = perturb ? ub[m] : linspace01(m, NI);
+    int lo = 0, hi = nb;  // id = #{cdf <= u}: rank by (stable) double argsort minus m (nerfBlock.scala:89-90)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int id = lo;
+    const int below = max(id - 1, 0);
+    const int above = min(id, nb - 1);
+    float den = __fsub_rn(cdf[above], cdf[below]);
+    if (den < 1e-5f) den = 1.0f;
+    const float t = __fdiv_rn(__fsub_rn(u, cdf[below]), den);
+    const float s = __fadd_rn(bins[below], __fmul_rn(t, __fsub_rn(bins[above], bins[below])));
+    sb[m] = s;
+    if (live) {
+      if (ind_out) ind_out[ray * NI + m] = id;
+      if (zs_out) zs_out[ray * NI + m] = s;
+    }
+  }
+  for (int i = lane; i < P - NI; i += 64) sb[NI + i] = (i < N) ? zr[i] : __builtin_inff();
+  __syncthreads();
+  bitonic_sort_lds(sb, P, lane);  // sort(concat(samples, z))  (nerfBlock.scala:101)
+  if (live)
+    for (int i = lane; i < N + NI; i += 64) z_fine[ray * (N + NI) + i] = sb[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// ray generation (getDataSet.scala:12-21,105-112; llff.scala:96-132) and uint8 conversion
+// ---------------------------------------------------------------------------------------------
+struct Pose { float m[12]; };
+
+__global__ void gen_rays_kernel(int H, int Wd, float focal, Pose c2w, float near, float far, int use_ndc,
+                                float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ bounds) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (int64_t)H * Wd) return;
+  const int j = (int)(p / Wd), i = (int)(p - (int64_t)j * Wd);
+  const float halfW = (float)(Wd * .5), halfH = (float)(H * .5);
+  const float dir0 = __fdiv_rn(__fsub_rn((float)i, halfW), focal);
+  const float dir1 = -__fdiv_rn(__fsub_rn((float)j, halfH), focal);
+  const float dir2 = -1.0f;
+  float d[3], o[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    d[k] = __fadd_rn(__fadd_rn(__fmul_rn(dir0, c2w.m[k * 4 + 0]), __fmul_rn(dir1, c2w.m[k * 4 + 1])),
+                     __fmul_rn(dir2, c2w.m[k * 4 + 2]));
+    o[k] = c2w.m[k * 4 + 3];
+  }
+  if (use_ndc) {
+    const float nr = 1.0f;
+    const float t = __fdiv_rn(__fadd_rn(o[2], nr), d[2]);
+    const float o0 = __fsub_rn(o[0], __fmul_rn(t, d[0])), o1 = __fsub_rn(o[1], __fmul_rn(t, d[1])),
+                o2 = __fsub_rn(o[2], __fmul_rn(t, d[2]));
+    const float sx = __fdiv_rn(-1.0f, __fdiv_rn((float)Wd, __fmul_rn(2.0f, focal)));
+    const float sy = __fdiv_rn(-1.0f, __fdiv_rn((float)H, __fmul_rn(2.0f, focal)));
+    const float n0 = __fmul_rn(__fdiv_rn(o0, o2), sx), n1 = __fmul_rn(__fdiv_rn(o1, o2), sy);
+    const float n2 = __fadd_rn(__fdiv_rn(2.0f * nr, o2), 1.0f);
+    const float e0 = __fmul_rn(__fsub_rn(__fdiv_rn(d[0], d[2]), __fdiv_rn(o0, o2)), sx);
+    const float e1 = __fmul_rn(__fsub_rn(__fdiv_rn(d[1], d[2]), __fdiv_rn(o1, o2)), sy);
+    const float e2 = __fdiv_rn(-2.0f * nr, o2);
+    o[0] = n0; o[1] = n1; o[2] = n2;
+    d[0] = e0; d[1] = e1; d[2] = e2;
+  }
+  const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rays_o[p * 3 + k] = o[k];
+    rays_d[p * 3 + k] = __fdiv_rn(d[k], nrm);
+  }
+  bounds[p * 2] = use_ndc ? 0.f : __fmul_rn(nrm, near);
+  bounds[p * 2 + 1] = use_ndc ? nrm : __fmul_rn(nrm, far);
+}
+
+__global__ void to_u8_kernel(const float* __restrict__ rgb, int64_t n, uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = __fmul_rn(rgb[i], 255.0f);
+  v = fminf(fmaxf(v, 0.f), 255.f);
+  out[i] = (uint8_t)v;  // truncation, as NDArray.toType(UINT8)
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+hipError_t launch_stratified(const float* bounds, const float* t_rand, int64_t n, int N, int lin_disp, int perturb,
+                             uint64_t seed, uint32_t step, float* z, hipStream_t s) {
+  const int64_t total = n * N;
+  hipLaunchKernelGGL(stratified_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, bounds, t_rand, n, N,
+                     lin_disp, perturb, seed, step, z);
+  return hipGetLastError();
+}
+
+hipError_t launch_composite_fwd(const float* sigma, const float* noise, const float* craw, const float* z, int64_t n,
+                                int S, float noise_std, int white, uint64_t seed, uint32_t step, uint32_t stream,
+                                float* w, float* rgb, float* depth, float* acc, hipStream_t s) {
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, sigma, noise, craw, z, n, S,
+                     noise_std, white, seed, step, stream, w, rgb, depth, acc);
+  return hipGetLastError();
+}
+
+hipError_t launch_composite_bwd(const float* sigma, const float* noise, const float* craw, const float* z,
+                                const float* d_rgb, int64_t n, int S, float noise_std, int white, uint64_t seed,
+                                uint32_t step, uint32_t stream, float* d_sigma, float* d_craw, hipStream_t s) {
+  const int Spad = (S + 3) & ~3;
+  const size_t lds = (size_t)4 * 3 * Spad * sizeof(float);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, s, sigma, noise, craw, z,
+                     d_rgb, n, S, Spad, noise_std, white, seed, step, stream, d_sigma, d_craw);
+  return hipGetLastError();
+}
+
+hipError_t launch_sample_pdf(const float* w, const float* z, const float* u_rand, int64_t n, int N, int NI, int perturb,
+                             uint64_t seed, uint32_t step, float* cdf, int32_t* ind, float* zs, float* z_fine,
+                             hipStream_t s) {
+  const int Npad = (N + 3) & ~3;
+  const int P = next_pow2(N + NI);
+  const int PU = perturb ? next_pow2(NI) : 0;
+  const size_t lds = (size_t)4 * (2 * Npad + P + PU) * sizeof(float);
+  if (lds > 64 * 1024 || N < 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, s, w, z, u_rand, n, N, NI, Npad,
+                     P, PU, perturb, seed, step, cdf, ind, zs, z_fine);
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float near, float far, int use_ndc,
+                           float* rays_o, float* rays_d, float* bounds, hipStream_t s) {
+  Pose p;
+  for (int i = 0; i < 12; ++i) p.m[i] = c2w[i];
+  const int64_t total = (int64_t)H * Wd;
+  hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, H, Wd, focal, p, near,
+                     far, use_ndc, rays_o, rays_d, bounds);
+  return hipGetLastError();
+}
+
+hipError_t launch_to_u8(const float* rgb, int64_t n, uint8_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(to_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rgb, n, out);
+  return hipGetLastError();
+}
+
+}  // namespace nh
