@@ -1,0 +1,724 @@
+// api.hip -- host side of libnerfhip.so: the C ABI of include/nerfhip.h, orchestration of the hot path
+// (nerfBlock.forwardWithCoarse / forwardWithoutCoarse, nerfBlock.scala:108-127) and the train step
+// (runNerf.scala:94-106).  Plain HIP runtime; no torch, no Python.  Fails loudly: every HIP error is
+// turned into a NERFHIP_E_* code with text; there is NO CPU fallback anywhere in this library.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "launchers.h"
+#include "rng.cuh"
+
+using namespace nh;
+
+namespace {
+std::string g_create_error;
+
+struct Net {
+  NetLayout L{};
+  int HT = 1, WT = 1;
+  int64_t param_off = 0;  // offset of this network in the flat parameter buffer
+  std::vector<ChunkDesc> fwd_desc, bwd_desc;
+  std::vector<uint32_t> off_fwd, off_bwd;
+  int n_fwd_trunk = 0;
+  ChunkDesc* d_fwd_desc = nullptr;
+  ChunkDesc* d_bwd_desc = nullptr;
+  uint32_t* d_off_fwd = nullptr;
+  uint32_t* d_off_bwd = nullptr;
+  float* d_wpack_fwd = nullptr;
+  float* d_wpack_bwd = nullptr;
+  float* d_vecpack = nullptr;
+  float* d_dirfeat = nullptr;  // [max_rays][max(32*HT, 12)]
+  float* d_encdirT = nullptr;  // training, mode 1: [32][Bpad]
+  ActStore st{};               // training activation store (allocated on first training call)
+  float* d_dsigma = nullptr;   // [max_rays][S]
+  float* d_dcraw = nullptr;    // [max_rays][S][3]
+};
+
+enum ProfClass { P_MLP_FWD = 0, P_MLP_BWD, P_WGRAD, P_COMPOSITE, P_SAMPLING, P_OTHER, P_NCLASS };
+struct ProfRec { int cls; hipEvent_t a, b; };
+}  // namespace
+
+struct nerfhip {
+  nerfhip_config cfg{};
+  int nnets = 1;
+  Net nets[2];
+  int64_t nparams = 0;
+  int N = 0, NI = 0, S = 0;
+  int64_t R = 0;  // max rays per call
+  float* d_params = nullptr;
+  float* d_grads = nullptr;
+  float* d_m = nullptr;
+  float* d_v = nullptr;
+  int64_t opt_step = 0;
+  uint32_t rng_step = 0;
+  bool grads_ready = false;
+  bool packed = false;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  // workspace (device)
+  float *w_o = nullptr, *w_d = nullptr, *w_b = nullptr, *w_v = nullptr, *w_label = nullptr;
+  float *w_rgb_f = nullptr, *w_rgb_c = nullptr, *w_depth = nullptr, *w_acc = nullptr, *w_drgb = nullptr;
+  float *w_zc = nullptr, *w_sigc = nullptr, *w_wc = nullptr, *w_crawc = nullptr;
+  float *w_zf = nullptr, *w_sigf = nullptr, *w_wf = nullptr, *w_crawf = nullptr;
+  float *w_trand = nullptr, *w_urand = nullptr, *w_noisec = nullptr, *w_noisef = nullptr;
+  uint8_t* w_u8 = nullptr;
+  double* d_loss = nullptr;  // [2]
+  bool train_ws = false;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  double flop_fwd = 0, flop_bwd = 0, flop_wgrad = 0;
+  int fwd_launches = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(nerfhip* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+#define HIPCHK(h, expr)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(h, e_ == hipErrorOutOfMemory ? NERFHIP_E_NOMEM : NERFHIP_E_HIP,                \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+  } while (0)
+
+bool is_skip(const nerfhip_config& c, int i) {
+  for (int k = 0; k < c.n_skips; ++k)
+    if (c.skips[k] == i) return true;
+  return false;
+}
+
+NetLayout make_layout(const nerfhip_config& c) {
+  NetLayout L{};
+  L.D = c.D; L.W = c.W; L.E = 3 * (1 + 2 * c.pos_l); L.Ed = 3 * (1 + 2 * c.dir_l); L.H2 = c.W / 2;
+  L.mode = c.use_dir ? (c.use_sh ? 2 : 1) : 0;
+  L.head_rows = L.mode == 1 ? L.H2 : (L.mode == 2 ? 27 : 3);
+  int64_t off = 0;
+  for (int l = 0; l < L.D; ++l) {
+    L.fan_in[l] = (l == 0) ? L.E : (L.W + (is_skip(c, l - 1) ? L.E : 0));
+    if (is_skip(c, l)) L.skip_mask |= 1u << l;
+    L.w_off[l] = off; off += (int64_t)L.W * L.fan_in[l];
+    L.b_off[l] = off; off += L.W;
+  }
+  L.ws_off = off; off += L.W;
+  L.bs_off = off; off += 1;
+  L.wf_off = off; off += (int64_t)L.head_rows * L.W;
+  L.bf_off = off; off += L.head_rows;
+  if (L.mode == 1) {
+    L.wd_off = off; off += (int64_t)L.H2 * L.Ed;
+    L.bd_off = off; off += L.H2;
+    L.wc_off = off; off += 3 * L.H2;
+    L.bc_off = off; off += 3;
+  }
+  L.count = off;
+  return L;
+}
+
+void build_chunks(Net& n) {
+  const NetLayout& L = n.L;
+  const int W = L.W, WT = n.WT, HT = n.HT;
+  uint32_t off = 0;
+  auto push = [&](std::vector<ChunkDesc>& v, std::vector<uint32_t>& offs, ChunkDesc d) {
+    d.dst_off = off;
+    offs.push_back(off);
+    off += 32u * (uint32_t)d.R;
+    v.push_back(d);
+  };
+  // forward stream
+  for (int l = 0; l < L.D; ++l) {
+    const bool uses_act = l > 0;
+    const bool uses_enc = l == 0 || ((L.skip_mask >> (l - 1)) & 1u);
+    if (uses_act)
+      for (int kt = 0; kt < WT; ++kt)
+        push(n.fwd_desc, n.off_fwd, ChunkDesc{L.w_off[l], L.fan_in[l], 0, 32 * kt, 32, W, W, 0, 0});
+    if (uses_enc)
+      for (int kt = 0; kt < 2; ++kt) {
+        const int kv = std::min(32, L.E - 32 * kt);
+        push(n.fwd_desc, n.off_fwd,
+             ChunkDesc{L.w_off[l], L.fan_in[l], 0, kv > 0 ? (uses_act ? W : 0) + 32 * kt : -1, std::max(kv, 0), W, W, 0, 0});
+      }
+  }
+  n.n_fwd_trunk = (int)n.fwd_desc.size();
+  for (int kt = 0; kt < WT; ++kt)
+    push(n.fwd_desc, n.off_fwd, ChunkDesc{L.wf_off, W, 0, 32 * kt, 32, L.head_rows, 32 * HT, 0, 0});
+  n.off_fwd.push_back(off);
+  // backward stream (transposed matrices)
+  off = 0;
+  for (int kt = 0; kt < HT; ++kt)
+    push(n.bwd_desc, n.off_bwd, ChunkDesc{L.wf_off, W, 1, 32 * kt, std::max(0, std::min(32, L.head_rows - 32 * kt)), W, W, 0, 0});
+  for (int l = L.D - 1; l >= 1; --l)
+    for (int kt = 0; kt < WT; ++kt)
+      push(n.bwd_desc, n.off_bwd, ChunkDesc{L.w_off[l], L.fan_in[l], 1, 32 * kt, 32, W, W, 0, 0});
+  n.off_bwd.push_back(off);
+}
+
+NetArgs net_args(const nerfhip* h, const Net& n) {
+  NetArgs a{};
+  a.params = h->d_params + n.param_off;
+  a.vecpack = n.d_vecpack;
+  a.wpack_fwd = n.d_wpack_fwd;
+  a.wpack_bwd = n.d_wpack_bwd;
+  a.off_fwd = n.d_off_fwd;
+  a.off_bwd = n.d_off_bwd;
+  a.n_fwd = (int)n.fwd_desc.size();
+  a.n_fwd_trunk = n.n_fwd_trunk;
+  a.n_bwd = (int)n.bwd_desc.size();
+  a.D = n.L.D; a.W = n.L.W; a.E = n.L.E; a.mode = n.L.mode; a.HT = n.HT; a.head_rows = n.L.head_rows; a.H2 = n.L.H2;
+  a.skip_mask = n.L.skip_mask;
+  return a;
+}
+
+template <typename T>
+hipError_t dalloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) return hipSuccess;
+  return hipMalloc((void**)p, count * sizeof(T));
+}
+
+// ---- profiling helpers -------------------------------------------------------------------------
+struct Scope {
+  nerfhip* h; int cls; hipEvent_t a = nullptr, b = nullptr;
+  Scope(nerfhip* h_, int cls_) : h(h_), cls(cls_) {
+    if (!h->prof_on) return;
+    auto get = [&]() { hipEvent_t e; if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); } else hipEventCreate(&e); return e; };
+    a = get(); b = get();
+    hipEventRecord(a, h->stream);
+  }
+  ~Scope() {
+    if (!h->prof_on) return;
+    hipEventRecord(b, h->stream);
+    h->prof.push_back(ProfRec{cls, a, b});
+  }
+};
+void prof_reset(nerfhip* h) {
+  for (auto& r : h->prof) { h->ev_pool.push_back(r.a); h->ev_pool.push_back(r.b); }
+  h->prof.clear();
+  h->flop_fwd = h->flop_bwd = h->flop_wgrad = 0;
+  h->fwd_launches = 0;
+}
+
+double net_fwd_flop_per_sample(const Net& n, bool want_rgb) {
+  const NetLayout& L = n.L;
+  double mac = 0;
+  for (int l = 0; l < L.D; ++l) mac += (double)L.W * L.fan_in[l];
+  mac += L.W;  // density head
+  if (want_rgb) {
+    mac += (double)L.head_rows * L.W;
+    if (L.mode == 1) mac += 3.0 * L.H2;
+  }
+  return 2.0 * mac;
+}
+
+int repack(nerfhip* h) {
+  Scope sc(h, P_OTHER);
+  for (int i = 0; i < h->nnets; ++i) {
+    Net& n = h->nets[i];
+    const float* p = h->d_params + n.param_off;
+    HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));
+    HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
+    HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
+  }
+  h->packed = true;
+  return NERFHIP_OK;
+}
+
+int dir_features(nerfhip* h, Net& n, const float* viewdir, int64_t nr, bool training) {
+  if (n.L.mode == 0) return NERFHIP_OK;
+  Scope sc(h, P_OTHER);
+  if (n.L.mode == 1)
+    HIPCHK(h, launch_dir_branch(h->d_params + n.param_off, n.L, 32 * n.HT, viewdir, nr, n.d_dirfeat,
+                                training ? n.d_encdirT : nullptr, (nr + 31) / 32 * 32, h->stream));
+  else
+    HIPCHK(h, launch_sh2(viewdir, nr, n.d_dirfeat, h->stream));
+  return NERFHIP_OK;
+}
+
+int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const float* d, const float* z, int64_t nr, int S,
+                float* sigma, float* craw, bool want_rgb) {
+  if (h->cfg.dtype != NERFHIP_F32) return fail(h, NERFHIP_E_INVALID, "bf16 MLP path not built in this version");
+  Scope sc(h, P_MLP_FWD);
+  ActStore st = n.st;
+  st.Mpad = (nr * S + kTile - 1) / kTile * kTile;
+  HIPCHK(h, launch_mlp_fwd_f32(train_store, net_args(h, n), o, d, z, n.d_dirfeat, nr * S, S, sigma, craw,
+                               want_rgb ? 1 : 0, st, h->stream));
+  h->flop_fwd += net_fwd_flop_per_sample(n, want_rgb) * (double)nr * S;
+  h->fwd_launches++;
+  return NERFHIP_OK;
+}
+
+struct DevIn { const float *o, *d, *b, *v; const float *t_rand, *u_rand, *noise_c, *noise_f; };
+
+// nerfBlock.forwardInternal on device buffers; results land in the workspace.
+int forward_dev(nerfhip* h, const DevIn& in, int64_t nr, bool training, bool train_store) {
+  if (nr <= 0 || nr > h->R) return fail(h, NERFHIP_E_INVALID, "n out of range (0 < n <= max_rays)");
+  if (!h->packed) { int rc = repack(h); if (rc) return rc; }
+  const nerfhip_config& c = h->cfg;
+  const int N = h->N, NI = h->NI, S = h->S;
+  const bool hier = c.use_hierarchical != 0;
+  const uint32_t step = h->rng_step++;
+  const float nstd = (training && c.raw_noise_std > 0.f) ? c.raw_noise_std : 0.f;
+  { Scope sc(h, P_SAMPLING);
+    HIPCHK(h, launch_stratified(in.b, in.t_rand, nr, N, c.lin_disp, c.perturb, c.seed, step, h->w_zc, h->stream)); }
+  Net& fine = h->nets[h->nnets - 1];
+  if (hier) {
+    Net& coarse = h->nets[0];
+    if (training) { int rc = dir_features(h, coarse, in.v, nr, train_store); if (rc) return rc; }
+    int rc = mlp_forward(h, coarse, train_store, in.o, in.d, h->w_zc, nr, N, h->w_sigc, h->w_crawc, training);
+    if (rc) return rc;
+    { Scope sc(h, P_COMPOSITE);
+      HIPCHK(h, launch_composite_fwd(h->w_sigc, in.noise_c, training ? h->w_crawc : nullptr, h->w_zc, nr, N, nstd,
+                                     c.white_bkgd, c.seed, step, kStreamNoiseC, h->w_wc, training ? h->w_rgb_c : nullptr,
+                                     nullptr, nullptr, h->stream)); }
+    { Scope sc(h, P_SAMPLING);
+      HIPCHK(h, launch_sample_pdf(h->w_wc, h->w_zc, in.u_rand, nr, N, NI, c.perturb, c.seed, step, nullptr, nullptr,
+                                  nullptr, h->w_zf, h->stream)); }
+  }
+  const float* zf = hier ? h->w_zf : h->w_zc;
+  int rc = dir_features(h, fine, in.v, nr, train_store);
+  if (rc) return rc;
+  rc = mlp_forward(h, fine, train_store, in.o, in.d, zf, nr, S, h->w_sigf, h->w_crawf, true);
+  if (rc) return rc;
+  { Scope sc(h, P_COMPOSITE);
+    HIPCHK(h, launch_composite_fwd(h->w_sigf, in.noise_f, h->w_crawf, zf, nr, S, nstd, c.white_bkgd, c.seed, step,
+                                   kStreamNoiseF, h->w_wf, h->w_rgb_f, h->w_depth, h->w_acc, h->stream)); }
+  return NERFHIP_OK;
+}
+
+int copy_out(nerfhip* h, void* dst, const void* src, size_t bytes, bool host) {
+  if (!dst) return NERFHIP_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, src, bytes, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
+  return NERFHIP_OK;
+}
+
+int export_aux(nerfhip* h, nerfhip_aux* a, int64_t nr, bool training, bool host) {
+  if (!a) return NERFHIP_OK;
+  const int N = h->N, S = h->S;
+  const bool hier = h->cfg.use_hierarchical != 0;
+  const size_t f = sizeof(float);
+  int rc = 0;
+  rc |= copy_out(h, a->z_coarse, h->w_zc, nr * N * f, host);
+  if (hier) {
+    rc |= copy_out(h, a->w_coarse, h->w_wc, nr * N * f, host);
+    rc |= copy_out(h, a->sigma_c, h->w_sigc, nr * N * f, host);
+    if (training) rc |= copy_out(h, a->craw_c, h->w_crawc, nr * N * 3 * f, host);
+  }
+  rc |= copy_out(h, a->z_fine, hier ? h->w_zf : h->w_zc, nr * S * f, host);
+  rc |= copy_out(h, a->w_fine, h->w_wf, nr * S * f, host);
+  rc |= copy_out(h, a->sigma_f, h->w_sigf, nr * S * f, host);
+  rc |= copy_out(h, a->craw_f, h->w_crawf, nr * S * 3 * f, host);
+  rc |= copy_out(h, a->depth, h->w_depth, nr * f, host);
+  rc |= copy_out(h, a->acc, h->w_acc, nr * f, host);
+  return rc ? NERFHIP_E_HIP : NERFHIP_OK;
+}
+
+// stage host inputs of one slice into the workspace
+int stage_in(nerfhip* h, const float* o, const float* d, const float* b, const float* v, const float* label,
+             const nerfhip_aux* a, int64_t off, int64_t nr, DevIn* in) {
+  const size_t f = sizeof(float);
+  auto up = [&](float* dst, const float* src, size_t per) -> hipError_t {
+    return hipMemcpyAsync(dst, src + off * per, nr * per * f, hipMemcpyHostToDevice, h->stream);
+  };
+  HIPCHK(h, up(h->w_o, o, 3));
+  HIPCHK(h, up(h->w_d, d, 3));
+  HIPCHK(h, up(h->w_b, b, 2));
+  HIPCHK(h, up(h->w_v, v, 3));
+  if (label) HIPCHK(h, up(h->w_label, label, 3));
+  *in = DevIn{h->w_o, h->w_d, h->w_b, h->w_v, nullptr, nullptr, nullptr, nullptr};
+  if (a) {
+    if (a->t_rand) { HIPCHK(h, up(h->w_trand, a->t_rand, h->N)); in->t_rand = h->w_trand; }
+    if (a->u_rand && h->NI > 0) { HIPCHK(h, up(h->w_urand, a->u_rand, h->NI)); in->u_rand = h->w_urand; }
+    if (a->noise_c) { HIPCHK(h, up(h->w_noisec, a->noise_c, h->N)); in->noise_c = h->w_noisec; }
+    if (a->noise_f) { HIPCHK(h, up(h->w_noisef, a->noise_f, h->S)); in->noise_f = h->w_noisef; }
+  }
+  return NERFHIP_OK;
+}
+
+nerfhip_aux aux_slice(const nerfhip_aux* a, int64_t off, int N, int S) {
+  nerfhip_aux s{};
+  if (!a) return s;
+  auto adv = [&](float* p, int64_t per) { return p ? p + off * per : nullptr; };
+  s.z_coarse = adv(a->z_coarse, N); s.w_coarse = adv(a->w_coarse, N);
+  s.z_fine = adv(a->z_fine, S); s.w_fine = adv(a->w_fine, S);
+  s.sigma_c = adv(a->sigma_c, N); s.sigma_f = adv(a->sigma_f, S);
+  s.craw_c = adv(a->craw_c, 3 * (int64_t)N); s.craw_f = adv(a->craw_f, 3 * (int64_t)S);
+  s.depth = adv(a->depth, 1); s.acc = adv(a->acc, 1);
+  return s;
+}
+
+int check_handle(nerfhip* h) {
+  if (!h) return fail(nullptr, NERFHIP_E_INVALID, "null handle");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return fail(h, NERFHIP_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  return NERFHIP_OK;
+}
+
+}  // namespace
+
+// training path lives in train.hip (same translation-unit-private structs are shared through this header-less
+// include to keep the handle layout in one place)
+#include "train_impl.inc"
+
+extern "C" {
+
+const char* nerfhip_version(void) { return "nerfhip 0.1 (gfx950, fp32 MFMA)"; }
+
+const char* nerfhip_last_error(const nerfhip_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
+  if (!cfg || !out) return fail(nullptr, NERFHIP_E_INVALID, "null argument");
+  *out = nullptr;
+  const nerfhip_config& c = *cfg;
+  auto bad = [&](const char* m) { return fail(nullptr, NERFHIP_E_INVALID, m); };
+  if (!(c.W == 32 || c.W == 64 || c.W == 128 || c.W == 256)) return bad("W must be 32, 64, 128 or 256");
+  if (c.D < 1 || c.D > kMaxD) return bad("D must be in [1,16]");
+  if (c.pos_l < 0 || c.pos_l > 10) return bad("posL must be in [0,10]");
+  if (c.use_dir && !c.use_sh && (c.dir_l < 0 || c.dir_l > 4)) return bad("dirL must be in [0,4]");
+  if (c.n_skips < 0 || c.n_skips > NERFHIP_MAX_SKIPS) return bad("too many skips");
+  for (int k = 0; k < c.n_skips; ++k)
+    if (c.skips[k] < 0 || c.skips[k] > c.D - 2) return bad("each skip must be in [0, D-2]");
+  if (c.n_samples < 3 || c.n_samples > 1024) return bad("NSamples must be in [3,1024]");
+  if (c.use_hierarchical && (c.n_importance < 1 || c.n_samples + c.n_importance > 2048))
+    return bad("NImportance must be >= 1 and NSamples+NImportance <= 2048");
+  if (c.max_rays < 1) return bad("max_rays must be >= 1");
+  if (c.dtype != NERFHIP_F32 && c.dtype != NERFHIP_BF16) return bad("unknown dtype");
+  if (c.lrate_decay <= 0) return bad("lrateDecay must be > 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(nullptr, NERFHIP_E_HIP, "no HIP device available (libnerfhip has no CPU path)");
+  if (c.device < 0 || c.device >= ndev) return bad("device ordinal out of range");
+  nerfhip* h = new nerfhip();
+  h->cfg = c;
+  if (hipSetDevice(c.device) != hipSuccess) { delete h; return fail(nullptr, NERFHIP_E_HIP, "hipSetDevice failed"); }
+  h->nnets = c.use_hierarchical ? 2 : 1;
+  h->N = c.n_samples;
+  h->NI = c.use_hierarchical ? c.n_importance : 0;
+  h->S = h->N + h->NI;
+  h->R = c.max_rays;
+  const NetLayout L = make_layout(c);
+  h->nparams = L.count * h->nnets;
+  auto cleanup_fail = [&](int code, const std::string& m) { g_create_error = m; nerfhip_destroy(h); return code; };
+#define CCHK(expr)                                                                                        \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                                      \
+      return cleanup_fail(e_ == hipErrorOutOfMemory ? NERFHIP_E_NOMEM : NERFHIP_E_HIP,                    \
+                          std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+  CCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  CCHK(dalloc(&h->d_params, h->nparams));
+  CCHK(dalloc(&h->d_grads, h->nparams));
+  CCHK(dalloc(&h->d_m, h->nparams));
+  CCHK(dalloc(&h->d_v, h->nparams));
+  CCHK(hipMemsetAsync(h->d_params, 0, h->nparams * sizeof(float), h->stream));
+  CCHK(hipMemsetAsync(h->d_grads, 0, h->nparams * sizeof(float), h->stream));
+  CCHK(hipMemsetAsync(h->d_m, 0, h->nparams * sizeof(float), h->stream));
+  CCHK(hipMemsetAsync(h->d_v, 0, h->nparams * sizeof(float), h->stream));
+  CCHK(dalloc(&h->d_loss, 2));
+  for (int i = 0; i < h->nnets; ++i) {
+    Net& n = h->nets[i];
+    n.L = L;
+    n.WT = c.W / 32;
+    n.HT = (L.head_rows + 31) / 32;
+    n.param_off = (int64_t)i * L.count;
+    build_chunks(n);
+    CCHK(dalloc(&n.d_fwd_desc, n.fwd_desc.size()));
+    CCHK(dalloc(&n.d_bwd_desc, std::max<size_t>(n.bwd_desc.size(), 1)));
+    CCHK(dalloc(&n.d_off_fwd, n.off_fwd.size()));
+    CCHK(dalloc(&n.d_off_bwd, n.off_bwd.size()));
+    CCHK(hipMemcpy(n.d_fwd_desc, n.fwd_desc.data(), n.fwd_desc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
+    if (!n.bwd_desc.empty())
+      CCHK(hipMemcpy(n.d_bwd_desc, n.bwd_desc.data(), n.bwd_desc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
+    CCHK(hipMemcpy(n.d_off_fwd, n.off_fwd.data(), n.off_fwd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CCHK(hipMemcpy(n.d_off_bwd, n.off_bwd.data(), n.off_bwd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CCHK(dalloc(&n.d_wpack_fwd, (size_t)n.off_fwd.back()));
+    CCHK(dalloc(&n.d_wpack_bwd, std::max<size_t>(n.off_bwd.back(), 4)));
+    CCHK(dalloc(&n.d_vecpack, (size_t)vecpack_floats(L.D, L.W)));
+    CCHK(dalloc(&n.d_dirfeat, (size_t)h->R * std::max(32 * n.HT, 12)));
+  }
+  const size_t R = (size_t)h->R, N = h->N, S = h->S, NI = std::max(h->NI, 1);
+  CCHK(dalloc(&h->w_o, R * 3)); CCHK(dalloc(&h->w_d, R * 3)); CCHK(dalloc(&h->w_b, R * 2)); CCHK(dalloc(&h->w_v, R * 3));
+  CCHK(dalloc(&h->w_label, R * 3)); CCHK(dalloc(&h->w_rgb_f, R * 3)); CCHK(dalloc(&h->w_rgb_c, R * 3));
+  CCHK(dalloc(&h->w_depth, R)); CCHK(dalloc(&h->w_acc, R)); CCHK(dalloc(&h->w_drgb, R * 3));
+  CCHK(dalloc(&h->w_zc, R * N)); CCHK(dalloc(&h->w_sigc, R * N)); CCHK(dalloc(&h->w_wc, R * N));
+  CCHK(dalloc(&h->w_crawc, R * N * 3));
+  CCHK(dalloc(&h->w_zf, R * S)); CCHK(dalloc(&h->w_sigf, R * S)); CCHK(dalloc(&h->w_wf, R * S));
+  CCHK(dalloc(&h->w_crawf, R * S * 3));
+  CCHK(dalloc(&h->w_trand, R * N)); CCHK(dalloc(&h->w_urand, R * NI)); CCHK(dalloc(&h->w_noisec, R * N));
+  CCHK(dalloc(&h->w_noisef, R * S));
+  CCHK(dalloc(&h->w_u8, R * 3));
+  CCHK(hipStreamSynchronize(h->stream));
+#undef CCHK
+  *out = h;
+  return NERFHIP_OK;
+}
+
+void nerfhip_destroy(nerfhip_t* h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  auto fr = [](void* p) { if (p) hipFree(p); };
+  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss);
+  for (int i = 0; i < 2; ++i) {
+    Net& n = h->nets[i];
+    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd);
+    fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT);
+    fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.d_dsigma); fr(n.d_dcraw);
+  }
+  fr(h->w_o); fr(h->w_d); fr(h->w_b); fr(h->w_v); fr(h->w_label); fr(h->w_rgb_f); fr(h->w_rgb_c); fr(h->w_depth);
+  fr(h->w_acc); fr(h->w_drgb); fr(h->w_zc); fr(h->w_sigc); fr(h->w_wc); fr(h->w_crawc); fr(h->w_zf); fr(h->w_sigf);
+  fr(h->w_wf); fr(h->w_crawf); fr(h->w_trand); fr(h->w_urand); fr(h->w_noisec); fr(h->w_noisef); fr(h->w_u8);
+  for (auto& r : h->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (auto e : h->ev_pool) hipEventDestroy(e);
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+int nerfhip_set_stream(nerfhip_t* h, void* s) {
+  int rc = check_handle(h); if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return NERFHIP_OK;
+}
+
+int nerfhip_synchronize(nerfhip_t* h) {
+  int rc = check_handle(h); if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return NERFHIP_OK;
+}
+
+int64_t nerfhip_param_count(const nerfhip_t* h) { return h ? h->nparams : 0; }
+
+int nerfhip_set_params(nerfhip_t* h, const float* src, int64_t n) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!src || n != h->nparams) return fail(h, NERFHIP_E_INVALID, "set_params: wrong size");
+  HIPCHK(h, hipMemcpyAsync(h->d_params, src, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return repack(h);
+}
+
+int nerfhip_get_params(nerfhip_t* h, float* dst, int64_t n) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!dst || n != h->nparams) return fail(h, NERFHIP_E_INVALID, "get_params: wrong size");
+  HIPCHK(h, hipMemcpyAsync(dst, h->d_params, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return NERFHIP_OK;
+}
+
+int nerfhip_init_params(nerfhip_t* h, uint64_t seed) {
+  int rc = check_handle(h); if (rc) return rc;
+  for (int i = 0; i < h->nnets; ++i) {
+    const Net& n = h->nets[i];
+    const NetLayout& L = n.L;
+    auto seg = [&](int64_t off, int64_t cnt, int fan_in) {
+      return launch_init(h->d_params, n.param_off + off, cnt, fan_in > 0 ? (float)std::sqrt(2.0 / fan_in) : 0.f, seed,
+                         h->stream);
+    };
+    for (int l = 0; l < L.D; ++l) {
+      HIPCHK(h, seg(L.w_off[l], (int64_t)L.W * L.fan_in[l], L.fan_in[l]));
+      HIPCHK(h, seg(L.b_off[l], L.W, 0));
+    }
+    HIPCHK(h, seg(L.ws_off, L.W, L.W));
+    HIPCHK(h, seg(L.bs_off, 1, 0));
+    HIPCHK(h, seg(L.wf_off, (int64_t)L.head_rows * L.W, L.W));
+    HIPCHK(h, seg(L.bf_off, L.head_rows, 0));
+    if (L.mode == 1) {
+      HIPCHK(h, seg(L.wd_off, (int64_t)L.H2 * L.Ed, L.Ed));
+      HIPCHK(h, seg(L.bd_off, L.H2, 0));
+      HIPCHK(h, seg(L.wc_off, 3 * L.H2, L.H2));
+      HIPCHK(h, seg(L.bc_off, 3, 0));
+    }
+  }
+  HIPCHK(h, hipMemsetAsync(h->d_m, 0, h->nparams * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_v, 0, h->nparams * sizeof(float), h->stream));
+  h->opt_step = 0;
+  return repack(h);
+}
+
+int nerfhip_get_opt_state(nerfhip_t* h, float* m, float* v, int64_t n, int64_t* step) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (n != h->nparams) return fail(h, NERFHIP_E_INVALID, "get_opt_state: wrong size");
+  if (m) HIPCHK(h, hipMemcpyAsync(m, h->d_m, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (v) HIPCHK(h, hipMemcpyAsync(v, h->d_v, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (step) *step = h->opt_step;
+  return NERFHIP_OK;
+}
+
+int nerfhip_set_opt_state(nerfhip_t* h, const float* m, const float* v, int64_t n, int64_t step) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (n != h->nparams || step < 0) return fail(h, NERFHIP_E_INVALID, "set_opt_state: bad argument");
+  if (m) HIPCHK(h, hipMemcpyAsync(h->d_m, m, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if (v) HIPCHK(h, hipMemcpyAsync(h->d_v, v, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->opt_step = step;
+  return NERFHIP_OK;
+}
+
+// ---- render -------------------------------------------------------------------------------------
+int nerfhip_render_dev(nerfhip_t* h, const float* o, const float* d, const float* b, const float* v, int64_t n,
+                       float* rgb, nerfhip_aux* aux) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!o || !d || !b || !v || !rgb) return fail(h, NERFHIP_E_INVALID, "render: null pointer");
+  prof_reset(h);
+  DevIn in{o, d, b, v, aux ? aux->t_rand : nullptr, aux ? aux->u_rand : nullptr, nullptr, nullptr};
+  rc = forward_dev(h, in, n, false, false);
+  if (rc) return rc;
+  rc = copy_out(h, rgb, h->w_rgb_f, n * 3 * sizeof(float), false);
+  if (rc) return rc;
+  return export_aux(h, aux, n, false, false);
+}
+
+int nerfhip_render(nerfhip_t* h, const float* o, const float* d, const float* b, const float* v, int64_t n, float* rgb,
+                   nerfhip_aux* aux) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!o || !d || !b || !v || !rgb || n < 0) return fail(h, NERFHIP_E_INVALID, "render: bad argument");
+  prof_reset(h);
+  for (int64_t off = 0; off < n; off += h->R) {
+    const int64_t nr = std::min<int64_t>(h->R, n - off);
+    DevIn in;
+    rc = stage_in(h, o, d, b, v, nullptr, aux, off, nr, &in);
+    if (rc) return rc;
+    rc = forward_dev(h, in, nr, false, false);
+    if (rc) return rc;
+    rc = copy_out(h, rgb + off * 3, h->w_rgb_f, nr * 3 * sizeof(float), true);
+    if (rc) return rc;
+    nerfhip_aux s = aux_slice(aux, off, h->N, h->S);
+    rc = export_aux(h, aux ? &s : nullptr, nr, false, true);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return NERFHIP_OK;
+}
+
+int nerfhip_render_u8(nerfhip_t* h, const float* o, const float* d, const float* b, const float* v, int64_t n,
+                      uint8_t* out) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!o || !d || !b || !v || !out || n < 0) return fail(h, NERFHIP_E_INVALID, "render_u8: bad argument");
+  prof_reset(h);
+  for (int64_t off = 0; off < n; off += h->R) {
+    const int64_t nr = std::min<int64_t>(h->R, n - off);
+    DevIn in;
+    rc = stage_in(h, o, d, b, v, nullptr, nullptr, off, nr, &in);
+    if (rc) return rc;
+    rc = forward_dev(h, in, nr, false, false);
+    if (rc) return rc;
+    HIPCHK(h, launch_to_u8(h->w_rgb_f, nr * 3, h->w_u8, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out + off * 3, h->w_u8, nr * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return NERFHIP_OK;
+}
+
+int nerfhip_forward_train(nerfhip_t* h, const float* o, const float* d, const float* b, const float* v, int64_t n,
+                          float* rgb_fine, float* rgb_coarse, nerfhip_aux* aux) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!o || !d || !b || !v || !rgb_fine || n < 0) return fail(h, NERFHIP_E_INVALID, "forward_train: bad argument");
+  prof_reset(h);
+  for (int64_t off = 0; off < n; off += h->R) {
+    const int64_t nr = std::min<int64_t>(h->R, n - off);
+    DevIn in;
+    rc = stage_in(h, o, d, b, v, nullptr, aux, off, nr, &in);
+    if (rc) return rc;
+    rc = forward_dev(h, in, nr, true, false);
+    if (rc) return rc;
+    rc = copy_out(h, rgb_fine + off * 3, h->w_rgb_f, nr * 3 * sizeof(float), true);
+    if (rc) return rc;
+    if (rgb_coarse && h->cfg.use_hierarchical) {
+      rc = copy_out(h, rgb_coarse + off * 3, h->w_rgb_c, nr * 3 * sizeof(float), true);
+      if (rc) return rc;
+    }
+    nerfhip_aux s = aux_slice(aux, off, h->N, h->S);
+    rc = export_aux(h, aux ? &s : nullptr, nr, true, true);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return NERFHIP_OK;
+}
+
+// ---- single kernels -------------------------------------------------------------------------------
+int nerfhip_k_stratified(nerfhip_t* h, const float* bounds, const float* t_rand, int64_t n, float* z) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!bounds || !z || n <= 0) return fail(h, NERFHIP_E_INVALID, "k_stratified: bad argument");
+  HIPCHK(h, launch_stratified(bounds, t_rand, n, h->N, h->cfg.lin_disp, h->cfg.perturb, h->cfg.seed, h->rng_step++, z,
+                              h->stream));
+  return NERFHIP_OK;
+}
+
+int nerfhip_k_composite_fwd(nerfhip_t* h, const float* sigma, const float* noise, const float* craw, const float* z,
+                            int64_t n, int32_t S, float* w, float* rgb, float* depth, float* acc) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!sigma || !z || n <= 0 || S < 2) return fail(h, NERFHIP_E_INVALID, "k_composite_fwd: bad argument");
+  HIPCHK(h, launch_composite_fwd(sigma, noise, craw, z, n, S, noise ? h->cfg.raw_noise_std : 0.f, h->cfg.white_bkgd,
+                                 h->cfg.seed, 0, kStreamNoiseF, w, rgb, depth, acc, h->stream));
+  return NERFHIP_OK;
+}
+
+int nerfhip_k_composite_bwd(nerfhip_t* h, const float* sigma, const float* noise, const float* craw, const float* z,
+                            const float* d_rgb, int64_t n, int32_t S, float* d_sigma, float* d_craw) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!sigma || !z || !craw || !d_rgb || !d_sigma || !d_craw || n <= 0 || S < 2)
+    return fail(h, NERFHIP_E_INVALID, "k_composite_bwd: bad argument");
+  HIPCHK(h, launch_composite_bwd(sigma, noise, craw, z, d_rgb, n, S, noise ? h->cfg.raw_noise_std : 0.f,
+                                 h->cfg.white_bkgd, h->cfg.seed, 0, kStreamNoiseF, d_sigma, d_craw, h->stream));
+  return NERFHIP_OK;
+}
+
+int nerfhip_k_sample_pdf(nerfhip_t* h, const float* w, const float* z, const float* u_rand, int64_t n, float* cdf,
+                         int32_t* ind, float* z_samples, float* z_fine) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!w || !z || !z_fine || n <= 0 || h->NI < 1) return fail(h, NERFHIP_E_INVALID, "k_sample_pdf: bad argument");
+  HIPCHK(h, launch_sample_pdf(w, z, u_rand, n, h->N, h->NI, h->cfg.perturb, h->cfg.seed, h->rng_step++, cdf, ind,
+                              z_samples, z_fine, h->stream));
+  return NERFHIP_OK;
+}
+
+int nerfhip_k_mlp_forward(nerfhip_t* h, int32_t net, const float* o, const float* d, const float* v, const float* z,
+                          int64_t n, int32_t S, float* sigma, float* craw) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (net < 0 || net >= h->nnets || !o || !d || !v || !z || !sigma || n <= 0 || n > h->R || S < 1)
+    return fail(h, NERFHIP_E_INVALID, "k_mlp_forward: bad argument");
+  if (!h->packed) { rc = repack(h); if (rc) return rc; }
+  prof_reset(h);
+  Net& nn = h->nets[net];
+  if (craw) { rc = dir_features(h, nn, v, n, false); if (rc) return rc; }
+  return mlp_forward(h, nn, false, o, d, z, n, S, sigma, craw, craw != nullptr);
+}
+
+int nerfhip_k_gen_rays(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w, float near, float far,
+                       int32_t ndc, float* rays_o, float* rays_d, float* bounds) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (H < 1 || W < 1 || !c2w || !rays_o || !rays_d || !bounds) return fail(h, NERFHIP_E_INVALID, "k_gen_rays: bad argument");
+  HIPCHK(h, launch_gen_rays(H, W, focal, c2w, near, far, ndc, rays_o, rays_d, bounds, h->stream));
+  return NERFHIP_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------
+int nerfhip_set_profiling(nerfhip_t* h, int32_t on) {
+  if (!h) return NERFHIP_E_INVALID;
+  h->prof_on = on != 0;
+  return NERFHIP_OK;
+}
+
+int nerfhip_get_profile(nerfhip_t* h, nerfhip_prof* out) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!out) return fail(h, NERFHIP_E_INVALID, "null argument");
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  memset(out, 0, sizeof(*out));
+  float acc[P_NCLASS] = {0};
+  for (auto& r : h->prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) acc[r.cls] += ms;
+  }
+  out->mlp_fwd_ms = acc[P_MLP_FWD]; out->mlp_bwd_ms = acc[P_MLP_BWD]; out->mlp_wgrad_ms = acc[P_WGRAD];
+  out->composite_ms = acc[P_COMPOSITE]; out->sampling_ms = acc[P_SAMPLING]; out->other_ms = acc[P_OTHER];
+  out->mlp_fwd_launches = h->fwd_launches;
+  out->mlp_fwd_flop = h->flop_fwd; out->mlp_bwd_flop = h->flop_bwd; out->mlp_wgrad_flop = h->flop_wgrad;
+  return NERFHIP_OK;
+}
+
+}  // extern "C"
