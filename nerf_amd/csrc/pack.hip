@@ -102,7 +102,7 @@ __global__ void sh2_kernel(const float* __restrict__ viewdir, int64_t n, float* 
   if (ray >= n) return;
   const float x = viewdir[ray * 3], y = viewdir[ray * 3 + 1], z = viewdir[ray * 3 + 2];
   const float cosPhi = z;
-  const float sinPhi = __fsqrt_rn(-(__fsub_rn(__fmul_rn(z, z), 1.0f)));
+  const float sinPhi = sqrtf(-(__fsub_rn(__fmul_rn(z, z), 1.0f)));
   const bool small = sinPhi < 1e-5f;
   const float cosTheta = small ? 1.0f : __fdiv_rn(x, sinPhi);
   const float sinTheta = small ? 0.0f : __fdiv_rn(y, sinPhi);
@@ -154,7 +154,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     const float vi = __fadd_rn(__fmul_rn(v[i], b2), __fmul_rn(__fmul_rn(gi, gi), 1.0f - b2));
     m[i] = mi;
     v[i] = vi;
-    p[i] = __fsub_rn(p[i], __fdiv_rn(__fmul_rn(mi, lrp), __fadd_rn(__fsqrt_rn(vi), eps)));
+    p[i] = __fsub_rn(p[i], __fdiv_rn(__fmul_rn(mi, lrp), __fadd_rn(sqrtf(vi), eps)));
   }
 }
 

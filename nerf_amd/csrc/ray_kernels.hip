@@ -360,7 +360,7 @@ __global__ void gen_rays_kernel(int H, int Wd, float focal, Pose c2w, float near
     o[0] = n0; o[1] = n1; o[2] = n2;
     d[0] = e0; d[1] = e1; d[2] = e2;
   }
-  const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+  const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     rays_o[p * 3 + k] = o[k];
