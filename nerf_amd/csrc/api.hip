@@ -32,6 +32,7 @@ struct Net {
   float* d_vecpack = nullptr;
   float* d_dirfeat = nullptr;  // [max_rays][max(32*HT, 12)]
   float* d_encdirT = nullptr;  // training, mode 1: [32][Bpad]
+  float* d_ddirT = nullptr;    // training, mode 1: d(dirvec)^T [32*HT][Bpad]
   ActStore st{};               // training activation store (allocated on first training call)
   float* d_dsigma = nullptr;   // [max_rays][S]
   float* d_dcraw = nullptr;    // [max_rays][S][3]
@@ -53,7 +54,7 @@ struct nerfhip {
   float* d_m = nullptr;
   float* d_v = nullptr;
   int64_t opt_step = 0;
-  uint32_t rng_step = 0;
+  uint32_t rng_step = 0, last_rng_step = 0;
   bool grads_ready = false;
   bool packed = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -66,6 +67,9 @@ struct nerfhip {
   uint8_t* w_u8 = nullptr;
   double* d_loss = nullptr;  // [2]
   bool train_ws = false;
+  nh::WgradItem* d_items = nullptr;
+  std::vector<nh::WgradItem> items;
+  int wgrad_splits = 32;
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -263,6 +267,7 @@ int forward_dev(nerfhip* h, const DevIn& in, int64_t nr, bool training, bool tra
   const int N = h->N, NI = h->NI, S = h->S;
   const bool hier = c.use_hierarchical != 0;
   const uint32_t step = h->rng_step++;
+  h->last_rng_step = step;
   const float nstd = (training && c.raw_noise_std > 0.f) ? c.raw_noise_std : 0.f;
   { Scope sc(h, P_SAMPLING);
     HIPCHK(h, launch_stratified(in.b, in.t_rand, nr, N, c.lin_disp, c.perturb, c.seed, step, h->w_zc, h->stream)); }
@@ -462,11 +467,11 @@ void nerfhip_destroy(nerfhip_t* h) {
   hipSetDevice(h->cfg.device);
   if (h->stream) hipStreamSynchronize(h->stream);
   auto fr = [](void* p) { if (p) hipFree(p); };
-  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss);
+  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
     fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd);
-    fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT);
+    fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
     fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.d_dsigma); fr(n.d_dcraw);
   }
   fr(h->w_o); fr(h->w_d); fr(h->w_b); fr(h->w_v); fr(h->w_label); fr(h->w_rgb_f); fr(h->w_rgb_c); fr(h->w_depth);
@@ -564,7 +569,6 @@ int nerfhip_render_dev(nerfhip_t* h, const float* o, const float* d, const float
                        float* rgb, nerfhip_aux* aux) {
   int rc = check_handle(h); if (rc) return rc;
   if (!o || !d || !b || !v || !rgb) return fail(h, NERFHIP_E_INVALID, "render: null pointer");
-  prof_reset(h);
   DevIn in{o, d, b, v, aux ? aux->t_rand : nullptr, aux ? aux->u_rand : nullptr, nullptr, nullptr};
   rc = forward_dev(h, in, n, false, false);
   if (rc) return rc;
@@ -577,7 +581,6 @@ int nerfhip_render(nerfhip_t* h, const float* o, const float* d, const float* b,
                    nerfhip_aux* aux) {
   int rc = check_handle(h); if (rc) return rc;
   if (!o || !d || !b || !v || !rgb || n < 0) return fail(h, NERFHIP_E_INVALID, "render: bad argument");
-  prof_reset(h);
   for (int64_t off = 0; off < n; off += h->R) {
     const int64_t nr = std::min<int64_t>(h->R, n - off);
     DevIn in;
@@ -599,7 +602,6 @@ int nerfhip_render_u8(nerfhip_t* h, const float* o, const float* d, const float*
                       uint8_t* out) {
   int rc = check_handle(h); if (rc) return rc;
   if (!o || !d || !b || !v || !out || n < 0) return fail(h, NERFHIP_E_INVALID, "render_u8: bad argument");
-  prof_reset(h);
   for (int64_t off = 0; off < n; off += h->R) {
     const int64_t nr = std::min<int64_t>(h->R, n - off);
     DevIn in;
@@ -618,7 +620,6 @@ int nerfhip_forward_train(nerfhip_t* h, const float* o, const float* d, const fl
                           float* rgb_fine, float* rgb_coarse, nerfhip_aux* aux) {
   int rc = check_handle(h); if (rc) return rc;
   if (!o || !d || !b || !v || !rgb_fine || n < 0) return fail(h, NERFHIP_E_INVALID, "forward_train: bad argument");
-  prof_reset(h);
   for (int64_t off = 0; off < n; off += h->R) {
     const int64_t nr = std::min<int64_t>(h->R, n - off);
     DevIn in;
@@ -683,7 +684,6 @@ int nerfhip_k_mlp_forward(nerfhip_t* h, int32_t net, const float* o, const float
   if (net < 0 || net >= h->nnets || !o || !d || !v || !z || !sigma || n <= 0 || n > h->R || S < 1)
     return fail(h, NERFHIP_E_INVALID, "k_mlp_forward: bad argument");
   if (!h->packed) { rc = repack(h); if (rc) return rc; }
-  prof_reset(h);
   Net& nn = h->nets[net];
   if (craw) { rc = dir_features(h, nn, v, n, false); if (rc) return rc; }
   return mlp_forward(h, nn, false, o, d, z, n, S, sigma, craw, craw != nullptr);
@@ -701,6 +701,7 @@ int nerfhip_k_gen_rays(nerfhip_t* h, int32_t H, int32_t W, float focal, const fl
 int nerfhip_set_profiling(nerfhip_t* h, int32_t on) {
   if (!h) return NERFHIP_E_INVALID;
   h->prof_on = on != 0;
+  prof_reset(h);   // totals returned by get_profile accumulate from here
   return NERFHIP_OK;
 }
 

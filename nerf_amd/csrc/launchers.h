@@ -37,4 +37,24 @@ hipError_t launch_mlp_fwd_f32(bool train, const NetArgs& net, const float* rays_
                               const float* dirfeat, int64_t M, int S, float* sigma, float* craw, int want_rgb,
                               const ActStore& st, hipStream_t stream);
 
+// mlp_bwd.hip
+hipError_t launch_mlp_bwd_f32(const NetArgs& net, const float* d_sigma, const float* d_craw, const float* dirfeat,
+                              int64_t M, int S, int has_rgb, const ActStore& st, hipStream_t stream);
+
+// wgrad.hip
+struct WgradItem {
+  const float* A;
+  const float* B;
+  float* dW;
+  float* db;
+  int64_t ld;
+  int32_t a_rows, b_rows;
+  int32_t ldo, col0;
+  int32_t nchunks;
+  int32_t pad;
+};
+hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, int splits, hipStream_t s);
+hipError_t launch_ray_sum(const float* dh, int64_t ld, int rows, int64_t n, int S, float* out, int64_t ldo,
+                          hipStream_t s);
+
 }  // namespace nh

@@ -1,0 +1,164 @@
+// mlp_bwd.hip -- backward-data pass of the density/colour MLP on fp32 MFMA (gfx950).
+//
+// Reverse mode of nerfCoreBlock.forwardInternal (reference nerf/nerfCoreBlock.scala:17-112; the reference
+// gets it from libtorch autograd via DJL's GradientCollector, runNerf.scala:96-105).  Same transposed
+// formulation as the forward kernel (mlp_common.cuh): the gradient w.r.t. a layer's pre-activations,
+// dY_l^T (W x 32 samples per wave), lives in accumulator registers and is directly the B operand of
+//     dX^T = W_l^T . dY_l^T
+// with W_l^T streamed through LDS from the packed backward stream.  The ReLU masks come from the stored
+// activations of the training forward pass; every dY_l^T (and the head gradients) is stored
+// feature-major for the weight-gradient GEMM (wgrad.hip).  Positions carry no gradient, so layer 0 and
+// the encoding half of a skip input produce no dX.
+#include "mlp_common.cuh"
+
+namespace nh {
+
+template <int WT>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const float* __restrict__ d_sigma,
+                                                             const float* __restrict__ d_craw,
+                                                             const float* __restrict__ dirfeat, int64_t M, int S,
+                                                             int has_rgb, ActStore st) {
+  constexpr int R = 32 * WT;
+  constexpr int HTM = WT >= 2 ? WT / 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[2][32 * R];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int64_t m = (int64_t)blockIdx.x * kTile + wave * 32 + li;
+  const bool valid = m < M;
+  const int64_t mc = valid ? m : M - 1;
+  const int64_t ray = mc / S;
+  const float* vp = net.vecpack;
+  const int W = net.W, D = net.D, HT = net.HT, Rh = 32 * net.HT;
+  const int64_t Mp = st.Mpad;
+
+  ChunkPipe pipe;
+  pipe.wpack = (const float*)net.wpack_bwd;
+  pipe.off = net.off_bwd;
+  pipe.buf0 = lds[0];
+  pipe.buf1 = lds[1];
+  pipe.n = net.n_bwd;
+  pipe.wave = wave;
+  pipe.lane = lane;
+  pipe.c = 0;
+  if (!has_rgb) pipe.c = HT;  // skip the head chunks of the stream (coarse net without colour never trains; kept general)
+  if (pipe.c < pipe.n)
+    stage_chunk(pipe.wpack + pipe.off[pipe.c], (pipe.c & 1) ? pipe.buf1 : pipe.buf0, pipe.off[pipe.c + 1] - pipe.off[pipe.c],
+                wave, lane);
+
+  const float dsig = valid ? d_sigma[m] : 0.f;
+  float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f;
+  if (valid && has_rgb) { dc0 = d_craw[m * 3]; dc1 = d_craw[m * 3 + 1]; dc2 = d_craw[m * 3 + 2]; }
+
+  // ---- head backward: dh = d(loss)/d(head pre-activation), in operand layout
+  f32x16 dh[HTM];
+#pragma unroll
+  for (int t = 0; t < HTM; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[t][r] = 0.f;
+  if (has_rgb) {
+    if (net.mode == 1) {
+      const float* wc = vp + (D + 2) * W;
+#pragma unroll
+      for (int t = 0; t < HTM; ++t) {
+        if (t < HT) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 32 * t + 8 * q + 4 * h;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wc + row);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wc + Rh + row);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wc + 2 * Rh + row);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float hcv = st.hc[(int64_t)(row + j) * Mp + m];
+              const float g = fmaf(w2[j], dc2, fmaf(w1[j], dc1, w0[j] * dc0));
+              dh[t][4 * q + j] = hcv > 0.f ? g : 0.f;
+            }
+          }
+        }
+      }
+    } else if (net.mode == 2) {
+      const float* Y = dirfeat + ray * 12;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tile_row(0, r, h);
+        if (row < 27) {
+          const int j = row / 3, k = row - 3 * j;
+          dh[0][r] = (k == 0 ? dc0 : (k == 1 ? dc1 : dc2)) * Y[j];
+        }
+      }
+    } else {
+      if (h == 0) { dh[0][0] = dc0; dh[0][1] = dc1; dh[0][2] = dc2; }
+    }
+  }
+  // store head gradients feature-major: rows < Rh, then d sigma, then d craw^T
+#pragma unroll
+  for (int t = 0; t < HTM; ++t) {
+    if (t < HT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st.dh[(int64_t)tile_row(t, r, h) * Mp + m] = dh[t][r];
+    }
+  }
+  if (h == 0) {
+    st.dh[(int64_t)Rh * Mp + m] = dsig;
+    st.dh[(int64_t)(Rh + 1) * Mp + m] = dc0;
+    st.dh[(int64_t)(Rh + 2) * Mp + m] = dc1;
+    st.dh[(int64_t)(Rh + 3) * Mp + m] = dc2;
+  }
+
+  // ---- d feat = w_sigma * d sigma + Wf^T . dh
+  f32x16 acc[WT], g[WT];
+  {
+    const float* ws = vp + D * W;
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + 32 * t + 8 * q + 4 * h);
+        acc[t][4 * q + 0] = wv[0] * dsig; acc[t][4 * q + 1] = wv[1] * dsig;
+        acc[t][4 * q + 2] = wv[2] * dsig; acc[t][4 * q + 3] = wv[3] * dsig;
+      }
+  }
+  if (has_rgb) {
+#pragma unroll
+    for (int kt = 0; kt < HTM; ++kt)
+      if (kt < HT) mm_chunk<WT>(acc, dh[kt], pipe.next(), R, WT, li, h);
+  }
+
+  // ---- trunk, last layer first
+  for (int l = D - 1; l >= 0; --l) {
+    const float* a = st.act + (int64_t)l * W * Mp + m;
+    float* dy = st.dy + (int64_t)l * W * Mp + m;
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t o = (int64_t)tile_row(t, r, h) * Mp;
+        const float v = a[o] > 0.f ? acc[t][r] : 0.f;   // ReLU mask of layer l's output
+        g[t][r] = v;
+        dy[o] = v;
+      }
+    if (l > 0) {
+#pragma unroll
+      for (int t = 0; t < WT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < WT; ++kt) mm_chunk<WT>(acc, g[kt], pipe.next(), R, WT, li, h);
+    }
+  }
+}
+
+hipError_t launch_mlp_bwd_f32(const NetArgs& net, const float* d_sigma, const float* d_craw, const float* dirfeat,
+                              int64_t M, int S, int has_rgb, const ActStore& st, hipStream_t stream) {
+  const dim3 grid((unsigned)((M + kTile - 1) / kTile)), block(256);
+  switch (net.W / 32) {
+    case 1: hipLaunchKernelGGL((mlp_bwd_f32_kernel<1>), grid, block, 0, stream, net, d_sigma, d_craw, dirfeat, M, S, has_rgb, st); break;
+    case 2: hipLaunchKernelGGL((mlp_bwd_f32_kernel<2>), grid, block, 0, stream, net, d_sigma, d_craw, dirfeat, M, S, has_rgb, st); break;
+    case 4: hipLaunchKernelGGL((mlp_bwd_f32_kernel<4>), grid, block, 0, stream, net, d_sigma, d_craw, dirfeat, M, S, has_rgb, st); break;
+    case 8: hipLaunchKernelGGL((mlp_bwd_f32_kernel<8>), grid, block, 0, stream, net, d_sigma, d_craw, dirfeat, M, S, has_rgb, st); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace nh

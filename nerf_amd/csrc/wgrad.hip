@@ -1,0 +1,163 @@
+// wgrad.hip -- weight-gradient GEMM of the MLP on fp32 MFMA (gfx950), plus the small reductions around it.
+//
+//   dW[i][j] = sum_m  A[i][m] * B[j][m]          A = dY^T (gradient rows), B = X^T (input feature rows)
+// Both operands are stored feature-major [row][Mpad] by the forward/backward kernels, i.e. K(=sample)-
+// contiguous for BOTH MFMA operands ("NT" GEMM with a huge reduction dimension and a <=256x256 output).
+// One workgroup (4 waves, 1 per SIMD, 512-register file) owns a whole <=256x256 output tile in
+// accumulators (each wave 128x128 = 4x4 MFMA tiles = 256 registers) and walks a slice of the sample axis
+// in chunks of 32 samples staged by LDS-DMA into an XOR-swizzled image; slices of the sample axis are
+// combined with fp32 atomics into the (pre-zeroed) canonical gradient buffer: per 256x256 layer that is
+// `splits` x 256 KiB of atomic traffic, three orders of magnitude below the operand stream.
+// The k order inside an 8-sample group is permuted (lane half h takes samples 4h..4h+3) identically for A
+// and B, so one 16-byte LDS read feeds four MFMAs.
+#include "mlp_common.cuh"
+#include "launchers.h"
+
+namespace nh {
+
+
+constexpr int kWgRows = 256;                 // max rows per operand tile
+constexpr int kWgChunkFloats = kWgRows * 32; // one operand, one chunk: 256 rows x 32 samples
+
+// LDS image of one operand chunk: [row][8 x 16-byte slots], slot s of row r holds samples
+// 4*(s ^ swz(r)) .. +3 with swz(r) = (r >> 1) & 7  (conflict-free ds_read_b128 across 16 rows)
+__device__ __forceinline__ void stage_operand(const float* g, int64_t ld, int rows, int64_t m0, float* lds, int wave,
+                                              int lane) {
+  // wave-instruction u covers rows 8u..8u+7 (64 lanes x 16 B = 8 rows x 128 B)
+  const int nrow8 = (rows + 7) >> 3;
+  for (int u = wave; u < nrow8; u += 4) {
+    int r = 8 * u + (lane >> 3);
+    const int s = lane & 7;
+    const int rs = r < rows ? r : rows - 1;  // clamp: rows past the end duplicate the last row (never stored)
+    const int src_slot = s ^ ((r >> 1) & 7);
+    __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(g + (int64_t)rs * ld + m0 + 4 * src_slot),
+                                     NERFHIP_LPTR(lds + u * 256), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __restrict__ items, int splits) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers x (A chunk | B chunk)
+  const WgradItem it = items[blockIdx.x];
+  const int split = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int per = (it.nchunks + splits - 1) / splits;
+  const int c0 = split * per;
+  const int c1 = min(it.nchunks, c0 + per);
+  if (c0 >= c1) return;
+  const int wa = wave >> 1, wb = wave & 1;          // this wave: A rows [128 wa, +128) x B rows [128 wb, +128)
+  const int a_tiles = min(4, max(0, (it.a_rows - 128 * wa + 31) / 32));
+  const int b_tiles = min(4, max(0, (it.b_rows - 128 * wb + 31) / 32));
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum = 0.f;  // bias gradient of row `tid`
+
+  // buffer b: A chunk at smem + 2b*chunk, B chunk at smem + (2b+1)*chunk
+  stage_operand(it.A, it.ld, it.a_rows, (int64_t)c0 * 32, smem, wave, lane);
+  stage_operand(it.B, it.ld, it.b_rows, (int64_t)c0 * 32, smem + kWgChunkFloats, wave, lane);
+  for (int c = c0; c < c1; ++c) {
+    const int cur = (c - c0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 < c1) {
+      float* nb = smem + (cur ^ 1) * 2 * kWgChunkFloats;
+      stage_operand(it.A, it.ld, it.a_rows, (int64_t)(c + 1) * 32, nb, wave, lane);
+      stage_operand(it.B, it.ld, it.b_rows, (int64_t)(c + 1) * 32, nb + kWgChunkFloats, wave, lane);
+    }
+    const float* As = smem + cur * 2 * kWgChunkFloats;
+    const float* Bs = As + kWgChunkFloats;
+    if (it.db && tid < it.a_rows) {
+      const f32x4* row = reinterpret_cast<const f32x4*>(As + tid * 32);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { const f32x4 v = row[s]; bsum += (v[0] + v[1]) + (v[2] + v[3]); }
+    }
+#pragma unroll
+    for (int g8 = 0; g8 < 4; ++g8) {      // 8-sample group: lane half h takes samples 8 g8 + 4h .. +3
+      const int slot = 2 * g8 + h;
+      f32x4 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = 128 * wa + 32 * i + li;
+        af[i] = *reinterpret_cast<const f32x4*>(As + ra * 32 + 4 * (slot ^ ((ra >> 1) & 7)));
+        const int rb = 128 * wb + 32 * i + li;
+        bf[i] = *reinterpret_cast<const f32x4*>(Bs + rb * 32 + 4 * (slot ^ ((rb >> 1) & 7)));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < a_tiles) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < b_tiles) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][2], bf[j][2], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][3], bf[j][3], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // combine the sample-axis slices: fp32 atomics, 128 contiguous bytes per lane half per instruction
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < a_tiles) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < b_tiles) {
+          const int col = 128 * wb + 32 * j + li;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 128 * wa + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < it.a_rows && col < it.b_rows)
+              atomicAdd(it.dW + (int64_t)row * it.ldo + it.col0 + col, acc[i][j][r]);
+          }
+        }
+      }
+    }
+  }
+  if (it.db && tid < it.a_rows) atomicAdd(it.db + tid, bsum);
+}
+
+// d(dirvec)^T[j][ray] = sum over the ray's samples of dh[j][ray*S + s]   (one wave per (row, ray))
+__global__ __launch_bounds__(256) void ray_sum_kernel(const float* __restrict__ dh, int64_t ld, int rows, int64_t n,
+                                                      int S, float* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (int64_t)rows * n) return;
+  const int j = (int)(wid / n);
+  const int64_t ray = wid - (int64_t)j * n;
+  const float* p = dh + (int64_t)j * ld + ray * S;
+  float s = 0.f;
+  for (int i = lane; i < S; i += 64) s += p[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (lane == 0) out[(int64_t)j * ldo + ray] = s;
+}
+
+hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, int splits, hipStream_t s) {
+  if (nitems <= 0) return hipSuccess;
+  const size_t lds = (size_t)4 * kWgChunkFloats * sizeof(float);  // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(nitems, splits), dim3(256), lds, s, d_items, splits);
+  return hipGetLastError();
+}
+
+hipError_t launch_ray_sum(const float* dh, int64_t ld, int rows, int64_t n, int S, float* out, int64_t ldo,
+                          hipStream_t s) {
+  const int64_t waves = (int64_t)rows * n;
+  hipLaunchKernelGGL(ray_sum_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, dh, ld, rows, n, S, out, ldo);
+  return hipGetLastError();
+}
+
+}  // namespace nh
