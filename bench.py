@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native NeRF hot path (libnerfhip.so).
+
+Workload (BASELINE.json configs[1] / configs[3]): full NeRF coarse+fine (64+128 samples/ray), 8x256 MLP with
+skip at 4, posL 10 / dirL 4 view-direction head, synthetic Blender-style 400x400 scene, fp32 MFMA.
+  * a "step" = ONE training iteration (forward + L2 loss + backward + [grad all-reduce] + Adam) on
+    4096 rays per GPU (weak scaling; runNerf.scala:94-106), inputs already resident in HBM;
+  * after the timed train steps the same process renders 400x400 frames (160 000 rays each) and reports
+    render rays/s in the "render" object of the same JSON line.
+`value` is whole-job train-step rays/s (all ranks).  Launch: python bench.py --gpus 1, or under
+torch.distributed.run for N > 1 (one process per GPU, RCCL all-reduce of the flat gradient buffer).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+class DevArray:
+    """Exposes a raw device address to torch (CUDA array interface) -- zero-copy view of the gradient buffer."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=4096, help="training rays per GPU per step")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--render-frames", type=int, default=3)
+    ap.add_argument("--hw", type=int, default=400, help="synthetic image side")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nerf_amd import NerfBlock, NerfConfig
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    HW = args.hw
+    n_frame = HW * HW
+    B = args.rays
+    base = dict(useDir=True, useSH=False, useHierarchical=True, posL=10, dirL=4, D=8, W=256, skips=[4], NSamples=64,
+                NImportance=128, rawNoiseStd=0.0, whiteBkgd=True, linDisp=False, perturb=False, lrate=5e-4,
+                lrateDecay=250, device=local, dtype=args.dtype, seed=1234)
+    trainer = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=B)))
+    renderer = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame)))
+    trainer.set_stream(stream)
+    renderer.set_stream(stream)
+    trainer.init_params(7)                       # same seed on every rank: replicas start identical
+    renderer.set_params(trainer.get_params())
+
+    # ---- synthetic scene: camera on a sphere of radius 4 looking at the origin (blender.scala:142-145)
+    focal = 0.5 * HW / math.tan(0.5 * 0.6911112070083618)
+    th = 0.7 + 0.5 * rank
+    phi = math.pi / 6
+    cam = 4.0 * np.array([math.cos(th) * math.cos(phi), math.sin(th) * math.cos(phi), math.sin(phi)])
+    fwd = -cam / np.linalg.norm(cam)
+    right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    c2w = np.stack([right, up, -fwd, cam], 1).astype(np.float32)      # [3][4]
+    f32 = dict(dtype=torch.float32, device="cuda")
+    ro, rd, bd = torch.empty(n_frame, 3, **f32), torch.empty(n_frame, 3, **f32), torch.empty(n_frame, 2, **f32)
+    renderer.k_gen_rays(HW, HW, focal, c2w, 2.0, 6.0, False, ro, rd, bd)
+    torch.cuda.synchronize()
+    label_full = 0.5 + 0.5 * torch.sin(4.0 * rd + ro)                   # smooth analytic target image
+    gsel = torch.Generator(device="cpu").manual_seed(100 + rank)
+    idx = torch.randperm(n_frame, generator=gsel)[:B].cuda()
+    t_o, t_d, t_b, t_l = ro[idx].contiguous(), rd[idx].contiguous(), bd[idx].contiguous(), label_full[idx].contiguous()
+    gptr, gn = trainer.grad_buffer()
+    grad = torch.as_tensor(DevArray(gptr, gn), device="cuda") if world > 1 else None
+
+    def train_step():
+        if world == 1:
+            trainer.train_step_dev(t_o, t_d, t_b, t_d, t_l, B)
+        else:
+            trainer.train_backward_dev(t_o, t_d, t_b, t_d, t_l, B)
+            dist.all_reduce(grad)                                  # RCCL: one flat 4.24 MB message
+            trainer.optimizer_step(1.0 / world)                    # mean over devices
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        train_step()
+    torch.cuda.synchronize(); barrier()
+    trainer.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    prof = trainer.get_profile()
+    trainer.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    train_rays_s = world * B * args.steps / dt
+
+    # ---- render leg: whole 400x400 frames, ray-parallel, no collective
+    out = torch.empty(n_frame, 3, **f32)
+    renderer.set_params(trainer.get_params())
+    renderer.render_dev(ro, rd, bd, rd, n_frame, out)
+    torch.cuda.synchronize(); barrier()
+    renderer.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.render_frames):
+        renderer.render_dev(ro, rd, bd, rd, n_frame, out)
+    torch.cuda.synchronize(); barrier()
+    dtr = time.perf_counter() - t0
+    rprof = renderer.get_profile()
+    if world > 1:
+        t = torch.tensor([dtr], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dtr = float(t.item())
+    render_rays_s = world * n_frame * args.render_frames / dtr
+
+    # ---- roofline of the dominant kernel of the timed train region (HIP events on the launch stream)
+    kern = {"mlp_fwd": (prof["mlp_fwd_ms"], prof["mlp_fwd_flop"]), "mlp_bwd": (prof["mlp_bwd_ms"], prof["mlp_bwd_flop"]),
+            "mlp_wgrad": (prof["mlp_wgrad_ms"], prof["mlp_wgrad_flop"])}
+    dom = max(kern, key=lambda k: kern[k][0])
+    peak = PEAK_TFLOPS[args.dtype]
+    ach = kern[dom][1] / max(kern[dom][0], 1e-9) / 1e9
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None,
+                "ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kern.items()},
+                "tflops": {k: round(v[1] / max(v[0], 1e-9) / 1e9, 2) for k, v in kern.items()},
+                "other_ms_per_step": round((prof["composite_ms"] + prof["sampling_ms"] + prof["other_ms"]) / args.steps, 4)}
+    r_ach = rprof["mlp_fwd_flop"] / max(rprof["mlp_fwd_ms"], 1e-9) / 1e9
+    render = {"metric": "rays/sec (render)", "value": round(render_rays_s, 1), "unit": "rays/s",
+              "workload": f"{HW}x{HW} frame, {n_frame} rays/GPU/frame", "frames": args.render_frames,
+              "ms_per_frame": round(1e3 * dtr / args.render_frames, 3),
+              "samples_per_s": round(render_rays_s * 192, 1),
+              "roofline": {"kernel": "mlp_fwd", "bound": "mfma", "achieved": round(r_ach, 2), "peak": peak,
+                           "unit": "TFLOP/s", "frac": round(r_ach / peak, 4)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(base, t_o, t_d, t_b, t_l, args.cpu_seconds)
+
+    if rank == 0:
+        line = {"metric": "rays/sec (train step)", "value": round(train_rays_s, 1), "unit": "rays/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                "data": "synthetic",
+                "config": {"workload": "full NeRF coarse+fine 64+128 samples/ray, 8x256 MLP, synthetic 400x400 "
+                                       "Blender-style scene; train step = fwd+L2+bwd+Adam",
+                           "rays_per_gpu_per_step": B, "global_batch": B * world, "samples_per_ray": 192,
+                           "parallelism": f"dp{world}"},
+                "samples_per_s": round(train_rays_s * 256, 1),
+                "roofline": roofline, "render": render, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(base, t_o, t_d, t_b, t_l, seconds):
+    """The CPU restatement (oracle, kind "port") timed on this box's host cores on a bounded sample of the
+    same workload: train iterations on 256-ray slices of the same batch, then eval renders."""
+    from oracle.oracle import Oracle
+    import helpers as H
+    c = {k: v for k, v in base.items() if k not in ("device", "dtype", "seed", "maxRays")}
+    o = Oracle(c)
+    params = H.make_params(c, 3, bias_scale=0.0)
+    ro, rd, bd, lb = (x.cpu().numpy() for x in (t_o, t_d, t_b, t_l))
+    chunk = 256
+    m = np.zeros_like(params); v = np.zeros_like(params)
+    o.train_grads(params, ro[:32], rd[:32], bd[:32], rd[:32], lb[:32])   # warm-up
+    t0 = time.perf_counter(); done = 0; it = 0
+    while time.perf_counter() - t0 < seconds * 0.6:
+        s = (it * chunk) % (ro.shape[0] - chunk + 1)
+        r = o.train_grads(params, ro[s:s + chunk], rd[s:s + chunk], bd[s:s + chunk], rd[s:s + chunk], lb[s:s + chunk])
+        o.adam(params, r["grads"], m, v, it + 1)
+        done += chunk; it += 1
+    train = done / (time.perf_counter() - t0)
+    t0 = time.perf_counter(); rdone = 0; it = 0
+    while time.perf_counter() - t0 < seconds * 0.4:
+        s = (it * chunk) % (ro.shape[0] - chunk + 1)
+        o.forward(params, ro[s:s + chunk], rd[s:s + chunk], bd[s:s + chunk], rd[s:s + chunk])
+        rdone += chunk; it += 1
+    rend = rdone / (time.perf_counter() - t0)
+    return {"value": round(train, 2), "unit": "rays/s", "cores": o.num_threads(), "kind": "port",
+            "sample": f"{done} rays of the same 4096-ray batch in 256-ray train iterations (fwd+loss+bwd+Adam); "
+                      f"render: {rdone} rays", "render_value": round(rend, 2),
+            "note": "C++ restatement of the reference path (oracle/), OpenMP; the Scala/DJL reference cannot run here"}
+
+
+if __name__ == "__main__":
+    main()

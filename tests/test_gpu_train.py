@@ -130,7 +130,8 @@ def test_adam_step_matches_oracle(G):
     for bb in (blk, blk2):
         bb.train_backward(g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"])
         bb.optimizer_step()
-    np.testing.assert_array_equal(blk.get_params(), blk2.get_params())
+    # gradients are combined with fp32 atomics (arrival order varies): equal to rounding, not bitwise
+    np.testing.assert_allclose(blk.get_params(), blk2.get_params(), rtol=0, atol=1e-6)
     blk.close(); blk2.close()
 
 
