@@ -26,13 +26,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
 
 
-class DevArray:
-    """Exposes a raw device address to torch (CUDA array interface) -- zero-copy view of the gradient buffer."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,6 +42,7 @@ def main():
     import torch
     import torch.distributed as dist
     from nerf_amd import NerfBlock, NerfConfig
+    from nerf_amd.dp import grad_tensor
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,8 +84,7 @@ def main():
     gsel = torch.Generator(device="cpu").manual_seed(100 + rank)
     idx = torch.randperm(n_frame, generator=gsel)[:B].cuda()
     t_o, t_d, t_b, t_l = ro[idx].contiguous(), rd[idx].contiguous(), bd[idx].contiguous(), label_full[idx].contiguous()
-    gptr, gn = trainer.grad_buffer()
-    grad = torch.as_tensor(DevArray(gptr, gn), device="cuda") if world > 1 else None
+    grad = grad_tensor(trainer) if world > 1 else None   # zero-copy torch view of the flat gradient buffer
 
     def train_step():
         if world == 1:

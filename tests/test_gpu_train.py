@@ -175,3 +175,34 @@ def test_psnr_after_fixed_steps(G):
 
 def blk_first_loss(o, params, ro, rd, b, label):
     return o.train_grads(params, ro, rd, b, rd, label)["loss_fine"]
+
+
+def test_dp_path_world1_nccl(G):
+    """The data-parallel step (train_backward -> all_reduce on the library's gradient buffer viewed as a
+    torch tensor -> optimizer_step(1/world)) with a 1-rank RCCL group equals the plain train_step."""
+    import torch
+    import torch.distributed as dist
+    from nerf_amd.dp import DataParallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = H.CONFIGS["small_dir"]
+        g = load("small_dir_train")
+        params = H.make_params(c, 1)
+        a, b = G.make_block(c), G.make_block(c)
+        stream = torch.cuda.current_stream().cuda_stream
+        for blk in (a, b):
+            blk.set_params(params)
+            blk.set_stream(stream)
+        dp = DataParallel.for_block(a)
+        args = (g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"])
+        for _ in range(2):
+            dp.train_step(lambda: a.train_backward(*args))
+            b.train_step(*args)
+        gv = dp.grad_view().cpu().numpy()
+        np.testing.assert_allclose(gv, a.get_grads(), rtol=0, atol=0)     # the view IS the buffer
+        np.testing.assert_allclose(a.get_params(), b.get_params(), rtol=0, atol=1e-6)
+        a.close(); b.close()
+    finally:
+        dist.destroy_process_group()
