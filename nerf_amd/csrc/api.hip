@@ -2,6 +2,7 @@
 // (nerfBlock.forwardWithCoarse / forwardWithoutCoarse, nerfBlock.scala:108-127) and the train step
 // (runNerf.scala:94-106).  Plain HIP runtime; no torch, no Python.  Fails loudly: every HIP error is
 // turned into a NERFHIP_E_* code with text; there is NO CPU fallback anywhere in this library.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -69,7 +70,7 @@ struct nerfhip {
   bool train_ws = false;
   nh::WgradItem* d_items = nullptr;
   std::vector<nh::WgradItem> items;
-  int wgrad_splits = 32;
+  int wg_chunks = 192;   // 32-sample chunks per weight-gradient work entry
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -472,7 +473,7 @@ void nerfhip_destroy(nerfhip_t* h) {
     Net& n = h->nets[i];
     fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd);
     fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
-    fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.d_dsigma); fr(n.d_dcraw);
+    fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.st.mask); fr(n.d_dsigma); fr(n.d_dcraw);
   }
   fr(h->w_o); fr(h->w_d); fr(h->w_b); fr(h->w_v); fr(h->w_label); fr(h->w_rgb_f); fr(h->w_rgb_c); fr(h->w_depth);
   fr(h->w_acc); fr(h->w_drgb); fr(h->w_zc); fr(h->w_sigc); fr(h->w_wc); fr(h->w_crawc); fr(h->w_zf); fr(h->w_sigf);

@@ -65,6 +65,8 @@ struct ActStore {
   float* dy;     // [D][W][Mpad]   gradients w.r.t. the pre-activations (written by backward)
   float* dh;     // [HT*32 + 32][Mpad] head gradients: rows < HT*32 d(head pre-act), row HT*32 = d sigma,
                  //                    rows HT*32+1..+3 = d craw^T (mode 1)
+  uint32_t* mask;  // [(D+1)][2 (lane half)][4 words][Mpad] ReLU sign bits of act (slot D: hc): bit 16*(t&1)+r of
+                   // word t/2 <-> register r of tile t; lets the backward pass fetch 16 B instead of 512 B per layer
   int64_t Mpad;
 };
 

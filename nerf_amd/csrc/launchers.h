@@ -50,10 +50,9 @@ struct WgradItem {
   int64_t ld;
   int32_t a_rows, b_rows;
   int32_t ldo, col0;
-  int32_t nchunks;
-  int32_t pad;
+  int32_t c0, c1;      // slice of the sample axis in 32-sample chunks
 };
-hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, int splits, hipStream_t s);
+hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, hipStream_t s);
 hipError_t launch_ray_sum(const float* dh, int64_t ld, int rows, int64_t n, int S, float* out, int64_t ldo,
                           hipStream_t s);
 

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
   const float* vp = net.vecpack;
   const int W = net.W, D = net.D, HT = net.HT, Rh = 32 * net.HT;
   const int64_t Mp = st.Mpad;
+  const uint32_t voff = lane_off(h, Mp, m);
 
   ChunkPipe pipe;
   pipe.wpack = (const float*)net.wpack_bwd;
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
   if (has_rgb) {
     if (net.mode == 1) {
       const float* wc = vp + (D + 2) * W;
+      uint32_t hmask[2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) hmask[w] = (w < (HTM + 1) / 2) ? *mask_ptr(st.mask, D, h, w, Mp, m) : 0u;
 #pragma unroll
       for (int t = 0; t < HTM; ++t) {
         if (t < HT) {
@@ -69,9 +73,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
             const f32x4 w2 = *reinterpret_cast<const f32x4*>(wc + 2 * Rh + row);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float hcv = st.hc[(int64_t)(row + j) * Mp + m];
               const float g = fmaf(w2[j], dc2, fmaf(w1[j], dc1, w0[j] * dc0));
-              dh[t][4 * q + j] = hcv > 0.f ? g : 0.f;
+              dh[t][4 * q + j] = ((hmask[t >> 1] >> (16 * (t & 1) + 4 * q + j)) & 1u) ? g : 0.f;
             }
           }
         }
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
   for (int t = 0; t < HTM; ++t) {
     if (t < HT) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st.dh[(int64_t)tile_row(t, r, h) * Mp + m] = dh[t][r];
+      for (int r = 0; r < 16; ++r) *row_ptr(st.dh, tile_row_u(t, r), Mp, voff) = dh[t][r];
     }
   }
   if (h == 0) {
@@ -124,26 +127,44 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
       if (kt < HT) mm_chunk<WT>(acc, dh[kt], pipe.next(), R, WT, li, h);
   }
 
-  // ---- trunk, last layer first
+  // ---- trunk, last layer first.  The ReLU mask of layer l comes from 16 bytes of sign bits per lane
+  // (prefetched one layer ahead); dY_l^T is stored after the first weight chunk of the layer has been
+  // waited for, so the pipeline's vmcnt(0) does not sit behind 128 fresh stores.
+  constexpr int NW = (WT + 1) / 2;
+  uint32_t mcur[4] = {0u, 0u, 0u, 0u}, mnext[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int w = 0; w < NW; ++w) mcur[w] = *mask_ptr(st.mask, D - 1, h, w, Mp, m);
   for (int l = D - 1; l >= 0; --l) {
-    const float* a = st.act + (int64_t)l * W * Mp + m;
-    float* dy = st.dy + (int64_t)l * W * Mp + m;
+    float* dy = st.dy + (int64_t)l * W * Mp;
+    if (l > 0) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) mnext[w] = *mask_ptr(st.mask, l - 1, h, w, Mp, m);
+    }
 #pragma unroll
     for (int t = 0; t < WT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t o = (int64_t)tile_row(t, r, h) * Mp;
-        const float v = a[o] > 0.f ? acc[t][r] : 0.f;   // ReLU mask of layer l's output
-        g[t][r] = v;
-        dy[o] = v;
-      }
+      for (int r = 0; r < 16; ++r) g[t][r] = ((mcur[t >> 1] >> (16 * (t & 1) + r)) & 1u) ? acc[t][r] : 0.f;
+    auto store_dy = [&]() {
+#pragma unroll
+      for (int t = 0; t < WT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *row_ptr(dy, tile_row_u(t, r), Mp, voff) = g[t][r];
+    };
     if (l > 0) {
 #pragma unroll
       for (int t = 0; t < WT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < WT; ++kt) mm_chunk<WT>(acc, g[kt], pipe.next(), R, WT, li, h);
+      for (int kt = 0; kt < WT; ++kt) {
+        const float* ch = pipe.next();
+        if (kt == 0) store_dy();
+        mm_chunk<WT>(acc, g[kt], ch, R, WT, li, h);
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mcur[w] = mnext[w];
+    } else {
+      store_dy();
     }
   }
 }

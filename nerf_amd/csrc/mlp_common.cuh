@@ -81,6 +81,35 @@ __device__ __forceinline__ constexpr int tile_row(int t, int r, int h) {
   return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
 
+// Feature-major activation store addressing: element (row, m) of a [rows][Mp] fp32 buffer where
+// row = row_u + 4h (row_u wave-uniform).  Written as (uniform 64-bit base) + (32-bit per-lane byte offset)
+// so the compiler emits SGPR-base global loads/stores instead of one 64-bit VGPR address per row.
+__device__ __forceinline__ uint32_t lane_off(int h, int64_t Mp, int64_t m) { return (uint32_t)((4 * h * Mp + m) * 4); }
+__device__ __forceinline__ float* row_ptr(float* base, int64_t row_u, int64_t Mp, uint32_t voff) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base + row_u * Mp) + voff);
+}
+__device__ __forceinline__ const float* row_ptr(const float* base, int64_t row_u, int64_t Mp, uint32_t voff) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + row_u * Mp) + voff);
+}
+__device__ __forceinline__ constexpr int tile_row_u(int t, int r) { return 32 * t + (r & 3) + 8 * (r >> 2); }
+
+// ReLU sign bits of NT accumulator tiles, 2 tiles per 32-bit word
+template <int NT>
+__device__ __forceinline__ void relu_mask_words(const f32x16 (&a)[NT], uint32_t (&w)[4], int nt) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = 0u;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w[t >> 1] |= (a[t][r] > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
+    }
+  }
+}
+__device__ __forceinline__ uint32_t* mask_ptr(uint32_t* mask, int slot, int h, int w, int64_t Mp, int64_t m) {
+  return mask + ((int64_t)(slot * 8 + h * 4 + w)) * Mp + m;
+}
+
 // acc[t][4q..4q+3] = v[32t + 8q + 4h .. +3]   (v has >= 32*nt floats, 16-byte aligned rows of 4)
 template <int NT>
 __device__ __forceinline__ void load_rows(f32x16 (&acc)[NT], const float* v, int nt, int nvalid, int h) {

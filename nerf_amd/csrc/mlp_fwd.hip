@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   const int64_t ray = mc / S;
   const float* vp = net.vecpack;
   const int W = net.W, D = net.D;
+  const uint32_t voff = TRAIN ? lane_off(h, st.Mpad, m) : 0u;
 
   ChunkPipe pipe;
   pipe.wpack = (const float*)net.wpack_fwd;
@@ -59,15 +60,32 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st.enc[(int64_t)tile_row(t, r, h) * st.Mpad + m] = valid ? enc[t][r] : 0.f;
+      for (int r = 0; r < 16; ++r) *row_ptr(st.enc, tile_row_u(t, r), st.Mpad, voff) = valid ? enc[t][r] : 0.f;
   }
 
   f32x16 act[WT], acc[WT];
+  // TRAIN: the post-ReLU activations of layer l-1 are stored feature-major right AFTER the first weight chunk
+  // of layer l has been waited for, so the chunk pipeline's vmcnt(0) never sits behind 128 fresh stores.
+  auto store_act = [&](int l_done) {
+    float* dst = st.act + (int64_t)l_done * W * st.Mpad;
+#pragma unroll
+    for (int t = 0; t < WT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) *row_ptr(dst, tile_row_u(t, r), st.Mpad, voff) = valid ? act[t][r] : 0.f;
+    uint32_t mw[4];
+    relu_mask_words<WT>(act, mw, WT);
+#pragma unroll
+    for (int w = 0; w < (WT + 1) / 2; ++w) *mask_ptr(st.mask, l_done, h, w, st.Mpad, m) = valid ? mw[w] : 0u;
+  };
   for (int l = 0; l < D; ++l) {
     load_rows<WT>(acc, vp + l * W, WT, W, h);  // accumulator := bias
     if (l > 0) {
 #pragma unroll
-      for (int kt = 0; kt < WT; ++kt) mm_chunk<WT>(acc, act[kt], pipe.next(), R, WT, li, h);
+      for (int kt = 0; kt < WT; ++kt) {
+        const float* ch = pipe.next();
+        if (TRAIN && kt == 0) store_act(l - 1);
+        mm_chunk<WT>(acc, act[kt], ch, R, WT, li, h);
+      }
     }
     if (l == 0 || ((net.skip_mask >> (l - 1)) & 1u)) {
 #pragma unroll
@@ -77,14 +95,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
     for (int t = 0; t < WT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) act[t][r] = fmaxf(acc[t][r], 0.f);
-    if (TRAIN) {
-      float* dst = st.act + (int64_t)l * W * st.Mpad + m;
-#pragma unroll
-      for (int t = 0; t < WT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(int64_t)tile_row(t, r, h) * st.Mpad] = valid ? act[t][r] : 0.f;
-    }
   }
+  if (TRAIN && !want_rgb) store_act(D - 1);
 
   // density head (nerfCoreBlock.scala:39-40): dot over this lane's half of the features + the other half
   {
@@ -112,7 +124,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   if (net.mode == 1) load_rows<HTM>(hacc, dirfeat + ray * Rh, HT, Rh, h);   // Wd.enc(dir) + bd + bf, per ray
   else load_rows<HTM>(hacc, vp + (D + 1) * W, HT, Rh, h);                   // head bias (zero padded)
 #pragma unroll
-  for (int kt = 0; kt < WT; ++kt) mm_chunk<HTM>(hacc, act[kt], pipe.next(), Rh, HT, li, h);
+  for (int kt = 0; kt < WT; ++kt) {
+    const float* ch = pipe.next();
+    if (TRAIN && kt == 0) store_act(D - 1);
+    mm_chunk<HTM>(hacc, act[kt], ch, Rh, HT, li, h);
+  }
 
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   if (net.mode == 1) {
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
         for (int r = 0; r < 16; ++r) hacc[t][r] = fmaxf(hacc[t][r], 0.f);  // add().relu() (:67)
         if (TRAIN) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) st.hc[(int64_t)tile_row(t, r, h) * st.Mpad + m] = valid ? hacc[t][r] : 0.f;
+          for (int r = 0; r < 16; ++r) *row_ptr(st.hc, tile_row_u(t, r), st.Mpad, voff) = valid ? hacc[t][r] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -140,6 +156,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
           }
         }
       }
+    }
+    if (TRAIN) {
+      uint32_t mw[4];
+      relu_mask_words<HTM>(hacc, mw, HT);
+#pragma unroll
+      for (int w = 0; w < (HTM + 1) / 2; ++w) *mask_ptr(st.mask, D, h, w, st.Mpad, m) = valid ? mw[w] : 0u;
     }
     if (h == 0) {
       c0 += vp[(D + 5) * W + 1];

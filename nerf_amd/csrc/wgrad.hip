@@ -7,7 +7,9 @@
 // accumulators (each wave 128x128 = 4x4 MFMA tiles = 256 registers) and walks a slice of the sample axis
 // in chunks of 32 samples staged by LDS-DMA into an XOR-swizzled image; slices of the sample axis are
 // combined with fp32 atomics into the (pre-zeroed) canonical gradient buffer: per 256x256 layer that is
-// `splits` x 256 KiB of atomic traffic, three orders of magnitude below the operand stream.
+// (#slices) x 256 KiB of atomic traffic, two to three orders of magnitude below the operand stream.
+// The host cuts every (layer, network) into work entries of at most `wg_chunks` chunks so all workgroups carry
+// about the same work (the coarse network has 1/3 of the fine one's samples) and launches the longest first.
 // The k order inside an 8-sample group is permuted (lane half h takes samples 4h..4h+3) identically for A
 // and B, so one 16-byte LDS read feeds four MFMAs.
 #include "mlp_common.cuh"
@@ -35,14 +37,11 @@ __device__ __forceinline__ void stage_operand(const float* g, int64_t ld, int ro
   }
 }
 
-__global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __restrict__ items, int splits) {
+__global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __restrict__ items) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers x (A chunk | B chunk)
   const WgradItem it = items[blockIdx.x];
-  const int split = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
-  const int per = (it.nchunks + splits - 1) / splits;
-  const int c0 = split * per;
-  const int c1 = min(it.nchunks, c0 + per);
+  const int c0 = it.c0, c1 = it.c1;   // this work entry's slice of the sample axis, in 32-sample chunks
   if (c0 >= c1) return;
   const int wa = wave >> 1, wb = wave & 1;          // this wave: A rows [128 wa, +128) x B rows [128 wb, +128)
   const int a_tiles = min(4, max(0, (it.a_rows - 128 * wa + 31) / 32));
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(256) void ray_sum_kernel(const float* __restrict__ 
   if (lane == 0) out[(int64_t)j * ldo + ray] = s;
 }
 
-hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, int splits, hipStream_t s) {
+hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, hipStream_t s) {
   if (nitems <= 0) return hipSuccess;
   const size_t lds = (size_t)4 * kWgChunkFloats * sizeof(float);  // 128 KiB
   static bool attr_set = false;
@@ -149,7 +148,7 @@ hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, int splits, hi
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(nitems, splits), dim3(256), lds, s, d_items, splits);
+  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(nitems), dim3(256), lds, s, d_items);
   return hipGetLastError();
 }
 
