@@ -34,17 +34,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
 
   ChunkPipe pipe;
   pipe.wpack = (const float*)net.wpack_bwd;
-  pipe.off = net.off_bwd;
   pipe.buf0 = lds[0];
   pipe.buf1 = lds[1];
-  pipe.n = net.n_bwd;
+  pipe.cs_main = pipe.cs_tail = 32u * R;
+  pipe.n_main = pipe.n = net.n_bwd;
   pipe.wave = wave;
   pipe.lane = lane;
-  pipe.c = 0;
-  if (!has_rgb) pipe.c = HT;  // skip the head chunks of the stream (coarse net without colour never trains; kept general)
-  if (pipe.c < pipe.n)
-    stage_chunk(pipe.wpack + pipe.off[pipe.c], (pipe.c & 1) ? pipe.buf1 : pipe.buf0, pipe.off[pipe.c + 1] - pipe.off[pipe.c],
-                wave, lane);
+  pipe.prime(has_rgb ? 0 : HT);  // without a colour gradient the head chunks of the stream are skipped
 
   const float dsig = valid ? d_sigma[m] : 0.f;
   float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f;
@@ -124,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
   if (has_rgb) {
 #pragma unroll
     for (int kt = 0; kt < HTM; ++kt)
-      if (kt < HT) mm_chunk<WT>(acc, dh[kt], pipe.next(), R, WT, li, h);
+      if (kt < HT) mm_chunk_t<WT, R>(acc, dh[kt], pipe, li, h);
   }
 
   // ---- trunk, last layer first.  The ReLU mask of layer l comes from 16 bytes of sign bits per lane
@@ -157,9 +153,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
       for (int kt = 0; kt < WT; ++kt) {
-        const float* ch = pipe.next();
-        if (kt == 0) store_dy();
-        mm_chunk<WT>(acc, g[kt], ch, R, WT, li, h);
+        mm_chunk_t<WT, R>(acc, g[kt], pipe, li, h);
+        if (kt == 0) store_dy();   // behind the first chunk's MFMAs
       }
 #pragma unroll
       for (int w = 0; w < 4; ++w) mcur[w] = mnext[w];

@@ -24,7 +24,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
                                                              int want_rgb, ActStore st) {
   constexpr int R = 32 * WT;
   constexpr int HTM = WT >= 2 ? WT / 2 : 1;
-  __shared__ __attribute__((aligned(16))) float lds[2][32 * R];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
   const int64_t m = (int64_t)blockIdx.x * kTile + wave * 32 + li;
@@ -35,15 +34,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   const int W = net.W, D = net.D;
   const uint32_t voff = TRAIN ? lane_off(h, st.Mpad, m) : 0u;
 
-  ChunkPipe pipe;
-  pipe.wpack = (const float*)net.wpack_fwd;
-  pipe.off = net.off_fwd;
-  pipe.buf0 = lds[0];
-  pipe.buf1 = lds[1];
-  pipe.n = want_rgb ? net.n_fwd : net.n_fwd_trunk;
-  pipe.wave = wave;
-  pipe.lane = lane;
-  pipe.prime();
+  const float* wp = (const float*)net.wpack_fwd;   // packed weight stream, consumed front to back
 
   // sample position (raysO.add(raysD.mul(zVals)), nerfBlock.scala:65): separate mul and add
   const float zz = z[mc];
@@ -80,16 +71,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   for (int l = 0; l < D; ++l) {
     load_rows<WT>(acc, vp + l * W, WT, W, h);  // accumulator := bias
     if (l > 0) {
-#pragma unroll
-      for (int kt = 0; kt < WT; ++kt) {
-        const float* ch = pipe.next();
-        if (TRAIN && kt == 0) store_act(l - 1);
-        mm_chunk<WT>(acc, act[kt], ch, R, WT, li, h);
-      }
+      if (TRAIN) store_act(l - 1);
+      mm_layer_g<WT, R, WT>(acc, act, wp, li, h);
+      wp += WT * 32 * R;
     }
     if (l == 0 || ((net.skip_mask >> (l - 1)) & 1u)) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) mm_chunk<WT>(acc, enc[kt], pipe.next(), R, WT, li, h);
+      mm_layer_g<WT, R, 2>(acc, enc, wp, li, h);
+      wp += 2 * 32 * R;
     }
 #pragma unroll
     for (int t = 0; t < WT; ++t)
@@ -123,12 +111,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   f32x16 hacc[HTM];
   if (net.mode == 1) load_rows<HTM>(hacc, dirfeat + ray * Rh, HT, Rh, h);   // Wd.enc(dir) + bd + bf, per ray
   else load_rows<HTM>(hacc, vp + (D + 1) * W, HT, Rh, h);                   // head bias (zero padded)
+  if (TRAIN) store_act(D - 1);
 #pragma unroll
-  for (int kt = 0; kt < WT; ++kt) {
-    const float* ch = pipe.next();
-    if (TRAIN && kt == 0) store_act(D - 1);
-    mm_chunk<HTM>(hacc, act[kt], ch, Rh, HT, li, h);
-  }
+  for (int kt = 0; kt < WT; ++kt) mm_chunk<HTM>(hacc, act[kt], wp + kt * 32 * Rh, Rh, HT, li, h);
 
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   if (net.mode == 1) {
