@@ -441,8 +441,12 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
       CCHK(hipMemcpy(n.d_bwd_desc, n.bwd_desc.data(), n.bwd_desc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
     CCHK(hipMemcpy(n.d_off_fwd, n.off_fwd.data(), n.off_fwd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CCHK(hipMemcpy(n.d_off_bwd, n.off_bwd.data(), n.off_bwd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    CCHK(dalloc(&n.d_wpack_fwd, (size_t)n.off_fwd.back()));
-    CCHK(dalloc(&n.d_wpack_bwd, std::max<size_t>(n.off_bwd.back(), 4)));
+    // one chunk of padding behind each stream: the kernels' fragment prefetch runs a few tiles past the end
+    const size_t pad = (size_t)32 * c.W;
+    CCHK(dalloc(&n.d_wpack_fwd, (size_t)n.off_fwd.back() + pad));
+    CCHK(dalloc(&n.d_wpack_bwd, (size_t)n.off_bwd.back() + pad));
+    CCHK(hipMemsetAsync(n.d_wpack_fwd, 0, ((size_t)n.off_fwd.back() + pad) * sizeof(float), h->stream));
+    CCHK(hipMemsetAsync(n.d_wpack_bwd, 0, ((size_t)n.off_bwd.back() + pad) * sizeof(float), h->stream));
     CCHK(dalloc(&n.d_vecpack, (size_t)vecpack_floats(L.D, L.W)));
     CCHK(dalloc(&n.d_dirfeat, (size_t)h->R * std::max(32 * n.HT, 12)));
   }

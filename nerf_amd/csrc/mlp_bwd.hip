@@ -5,13 +5,33 @@
 // formulation as the forward kernel (mlp_common.cuh): the gradient w.r.t. a layer's pre-activations,
 // dY_l^T (W x 32 samples per wave), lives in accumulator registers and is directly the B operand of
 //     dX^T = W_l^T . dY_l^T
-// with W_l^T streamed through LDS from the packed backward stream.  The ReLU masks come from the stored
-// activations of the training forward pass; every dY_l^T (and the head gradients) is stored
-// feature-major for the weight-gradient GEMM (wgrad.hip).  Positions carry no gradient, so layer 0 and
+// with W_l^T read straight from the packed backward stream in L2 through the continuous fragment ring of
+// mlp_common.cuh.  The ReLU masks are the sign bitmasks written by the training forward pass; every dY_l^T
+// (and the head gradients) is stored feature-major for the weight-gradient GEMM (wgrad.hip), two rows per
+// tile step between the fragment loads.  Positions carry no gradient, so layer 0 and
 // the encoding half of a skip input produce no dX.
 #include "mlp_common.cuh"
 
 namespace nh {
+
+// side operations of one trunk layer: the ReLU mask words of the NEXT layer to be processed (loaded at step 0,
+// landed long before the layer ends) and the stores of this layer's dY^T
+template <int WT>
+struct BwdSide {
+  static constexpr int NW = (WT + 1) / 2;
+  using St = StoreSide<WT, WT * WT>;
+  St st;
+  const uint32_t* mask_next;   // slot base of layer l-1
+  uint32_t* mnext;
+  static constexpr int ops(int T) { return St::ops(T) + (T == 0 ? NW : 0); }
+  template <int T> __device__ __forceinline__ void issue() const {
+    if constexpr (T == 0) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) gload4u(mnext[w], mask_next + (int64_t)w * st.Mp, st.voff);
+    }
+    st.template issue<T>();
+  }
+};
 
 template <int WT>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const float* __restrict__ d_sigma,
@@ -20,7 +40,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
                                                              int has_rgb, ActStore st) {
   constexpr int R = 32 * WT;
   constexpr int HTM = WT >= 2 ? WT / 2 : 1;
-  __shared__ __attribute__((aligned(16))) float lds[2][32 * R];
+  constexpr bool kFast = WT >= 4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
   const int64_t m = (int64_t)blockIdx.x * kTile + wave * 32 + li;
@@ -32,15 +52,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
   const int64_t Mp = st.Mpad;
   const uint32_t voff = lane_off(h, Mp, m);
 
-  ChunkPipe pipe;
-  pipe.wpack = (const float*)net.wpack_bwd;
-  pipe.buf0 = lds[0];
-  pipe.buf1 = lds[1];
-  pipe.cs_main = pipe.cs_tail = 32u * R;
-  pipe.n_main = pipe.n = net.n_bwd;
-  pipe.wave = wave;
-  pipe.lane = lane;
-  pipe.prime(has_rgb ? 0 : HT);  // without a colour gradient the head chunks of the stream are skipped
+  // backward stream: HT head chunks (Wf^T), then WT chunks per trunk layer D-1 .. 1, all with R rows
+  const float* wp = (const float*)net.wpack_bwd;
+  const uint32_t fvoff = frag_voff(lane);
+  f32x4 fr[kNB][4];
 
   const float dsig = valid ? d_sigma[m] : 0.f;
   float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f;
@@ -89,20 +104,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
       if (h == 0) { dh[0][0] = dc0; dh[0][1] = dc1; dh[0][2] = dc2; }
     }
   }
-  // store head gradients feature-major: rows < Rh, then d sigma, then d craw^T
-#pragma unroll
-  for (int t = 0; t < HTM; ++t) {
-    if (t < HT) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) *row_ptr(st.dh, tile_row_u(t, r), Mp, voff) = dh[t][r];
-    }
-  }
+  // head gradients go out feature-major: rows < Rh, then d sigma, then d craw^T
   if (h == 0) {
     st.dh[(int64_t)Rh * Mp + m] = dsig;
     st.dh[(int64_t)(Rh + 1) * Mp + m] = dc0;
     st.dh[(int64_t)(Rh + 2) * Mp + m] = dc1;
     st.dh[(int64_t)(Rh + 3) * Mp + m] = dc2;
   }
+  auto store_dh = [&]() { store_tiles<HTM>(st.dh, dh, HT, Mp, voff); };
 
   // ---- d feat = w_sigma * d sigma + Wf^T . dh
   f32x16 acc[WT], g[WT];
@@ -117,49 +126,60 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
         acc[t][4 * q + 2] = wv[2] * dsig; acc[t][4 * q + 3] = wv[3] * dsig;
       }
   }
-  if (has_rgb) {
+  if constexpr (kFast) {
+    // The fragment ring is primed directly in front of its first part (asm loads are only in flight inside a
+    // part, mlp_common.cuh) and then runs through the whole stream.  The head chunks are walked even without a
+    // colour gradient (dh = 0 then), which keeps the control flow free of un-primed paths.
+    prime_frags(fr, wp, fvoff);
+    mm_layer_g<WT, R, 1>(acc, &dh[0], fr, wp, fvoff, StoreSide<1, WT>{&dh[0], st.dh, Mp, voff});
 #pragma unroll
-    for (int kt = 0; kt < HTM; ++kt)
-      if (kt < HT) mm_chunk_t<WT, R>(acc, dh[kt], pipe, li, h);
+    for (int kt = 1; kt < HTM; ++kt)
+      if (kt < HT)
+        mm_layer_g<WT, R, 1>(acc, &dh[kt], fr, wp + kt * 32 * R, fvoff, StoreSide<1, WT>{&dh[kt], st.dh + (int64_t)32 * kt * Mp, Mp, voff});
+  } else {
+    store_dh();
+    if (has_rgb) {
+#pragma unroll
+      for (int kt = 0; kt < HTM; ++kt)
+        if (kt < HT) mm_chunk<WT>(acc, dh[kt], wp + kt * 32 * R, R, WT, li, h);
+    }
   }
+  wp += HT * 32 * R;
 
-  // ---- trunk, last layer first.  The ReLU mask of layer l comes from 16 bytes of sign bits per lane
-  // (prefetched one layer ahead); dY_l^T is stored after the first weight chunk of the layer has been
-  // waited for, so the pipeline's vmcnt(0) does not sit behind 128 fresh stores.
+  // ---- trunk, last layer first.  The ReLU mask of layer l is 16 bytes of sign bits per lane, fetched one
+  // layer ahead; dY_l^T is stored while the layer's MFMAs run.
   constexpr int NW = (WT + 1) / 2;
   uint32_t mcur[4] = {0u, 0u, 0u, 0u}, mnext[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int w = 0; w < NW; ++w) mcur[w] = *mask_ptr(st.mask, D - 1, h, w, Mp, m);
   for (int l = D - 1; l >= 0; --l) {
     float* dy = st.dy + (int64_t)l * W * Mp;
-    if (l > 0) {
-#pragma unroll
-      for (int w = 0; w < NW; ++w) mnext[w] = *mask_ptr(st.mask, l - 1, h, w, Mp, m);
-    }
 #pragma unroll
     for (int t = 0; t < WT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[t][r] = ((mcur[t >> 1] >> (16 * (t & 1) + r)) & 1u) ? acc[t][r] : 0.f;
-    auto store_dy = [&]() {
-#pragma unroll
-      for (int t = 0; t < WT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) *row_ptr(dy, tile_row_u(t, r), Mp, voff) = g[t][r];
-    };
     if (l > 0) {
 #pragma unroll
       for (int t = 0; t < WT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      if constexpr (kFast) {
+        const BwdSide<WT> side{{g, dy, Mp, voff}, st.mask + (int64_t)((l - 1) * 8) * Mp, mnext};
+        mm_layer_g<WT, R, WT>(acc, g, fr, wp, fvoff, side);
+        // the mask loads were issued at step 0 and retired (in order) by the counted waits of the later steps
+        asm volatile("" : "+v"(mnext[0]), "+v"(mnext[1]), "+v"(mnext[2]), "+v"(mnext[3]));
+      } else {
 #pragma unroll
-      for (int kt = 0; kt < WT; ++kt) {
-        mm_chunk_t<WT, R>(acc, g[kt], pipe, li, h);
-        if (kt == 0) store_dy();   // behind the first chunk's MFMAs
+        for (int w = 0; w < NW; ++w) mnext[w] = *mask_ptr(st.mask, l - 1, h, w, Mp, m);
+        store_tiles<WT>(dy, g, WT, Mp, voff);
+#pragma unroll
+        for (int kt = 0; kt < WT; ++kt) mm_chunk<WT>(acc, g[kt], wp + kt * 32 * R, R, WT, li, h);
       }
+      wp += WT * 32 * R;
 #pragma unroll
       for (int w = 0; w < 4; ++w) mcur[w] = mnext[w];
     } else {
-      store_dy();
+      store_tiles<WT>(dy, g, WT, Mp, voff);
     }
   }
 }

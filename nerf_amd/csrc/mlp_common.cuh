@@ -4,7 +4,7 @@
 // sample on the MFMA lane and the features in the accumulator registers:
 //     H_{l+1}^T (W x 32)  =  W_l (W x K) . H_l^T (K x 32)        per wave, 32 samples per wave
 // so the 32x32 accumulator tile of one layer IS the B operand of the next layer's MFMAs with no lane
-// movement and no LDS round trip; only the weights (the A operand) stream through LDS.
+// movement and no LDS round trip; only the weights (the A operand) stream in (from L2, see below).
 //
 // v_mfma_f32_32x32x2_f32 operand maps (cdna_hip_programming.md section 3):
 //   A: lane l holds A[i = l&31][k = l>>5]      B: lane l holds B[k = l>>5][j = l&31]
@@ -12,8 +12,9 @@
 // Register r of an accumulator tile therefore holds feature row R0(r) = (r&3)+8*(r>>2) in lanes 0-31
 // and row R0(r)+4 in lanes 32-63: used as B it contracts exactly the k-pair (R0(r), R0(r)+4), and the
 // A operand must present W[i][32*kt + R0(r) + 4*(l>>5)].  With r = 4q+j that is k = 32kt + 8q + 4h + j:
-// four consecutive k for fixed (q,h), i.e. one 16-byte LDS read per four MFMAs from a chunk image laid
-// out [g = k/4 (8)][i (R)][k%4 (4)]  (g = 2q + h).
+// four consecutive k for fixed (q,h), i.e. one 16-byte read per four MFMAs.  Packed weight image ("chunk" =
+// 32 k-values x R rows, pack.hip): [ot = i/32][q][lane = 32h + i%32][j]  with k = 8q + 4h + j, so the four
+// fragments of one 32x32 output tile are 4 KiB contiguous and each wave-wide 16-byte load reads 1 KiB linearly.
 #pragma once
 #include "common.h"
 
@@ -25,51 +26,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NERFHIP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define NERFHIP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-// Asynchronous global -> LDS copy of one chunk (nfloats*4 bytes, a multiple of 4096): every wave moves
-// 1 KiB per instruction (16 B per lane, LDS destination = wave-uniform base + lane*16).
-__device__ __forceinline__ void stage_chunk(const float* g, float* lds, uint32_t nfloats, int wave, int lane) {
-  const uint32_t bytes = nfloats * 4u;
-  for (uint32_t off = (uint32_t)wave * 1024u; off < bytes; off += 4096u) {
-    __builtin_amdgcn_global_load_lds(NERFHIP_GPTR((const char*)g + off + lane * 16),
-                                     NERFHIP_LPTR((char*)lds + off), 16, 0, 0);
-  }
-}
-
-// Double-buffered weight-chunk pipeline.  acquire() makes chunk c visible to the whole workgroup (own DMA
-// landed + barrier: everyone is also done reading chunk c-1); prefetch() starts the DMA of chunk c+1 into
-// the other buffer and is called a few MFMAs INTO chunk c, so that the matrix pipe is already busy while the
-// DMA instructions issue.  Chunk offsets are arithmetic (no table loads on the critical path): the first
-// n_main chunks have cs_main floats each, the rest (the colour head of the forward stream) cs_tail.
-// All 256 threads must call both.
-struct ChunkPipe {
-  const float* wpack;
-  float* buf0;
-  float* buf1;
-  uint32_t cs_main, cs_tail;
-  int n_main, n, c, wave, lane;
-  __device__ __forceinline__ const float* src(int i) const {
-    return wpack + (i < n_main ? (uint32_t)i * cs_main : (uint32_t)n_main * cs_main + (uint32_t)(i - n_main) * cs_tail);
-  }
-  __device__ __forceinline__ void prime(int first) {
-    c = first;
-    if (c < n) stage_chunk(src(c), (c & 1) ? buf1 : buf0, c < n_main ? cs_main : cs_tail, wave, lane);
-  }
-  __device__ __forceinline__ const float* acquire() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    return (c & 1) ? buf1 : buf0;
-  }
-  __device__ __forceinline__ void prefetch() {
-    if (c + 1 < n) stage_chunk(src(c + 1), (c & 1) ? buf0 : buf1, (c + 1) < n_main ? cs_main : cs_tail, wave, lane);
-    ++c;
-  }
-  __device__ __forceinline__ const float* next() {  // acquire + immediate prefetch
-    const float* cur = acquire();
-    prefetch();
-    return cur;
-  }
-};
-
 // acc[ot] += A_chunk(rows 32*ot..) . b   for ot < nt (nt wave-uniform, <= NT); R = rows of the chunk (runtime).
 // Plain C++ version (used for the colour head, whose row count is a run-time value).
 template <int NT>
@@ -80,7 +36,7 @@ __device__ __forceinline__ void mm_chunk(f32x16 (&acc)[NT], const f32x16& b, con
     if (ot < nt) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(chunk + ((2 * q + h) * R + 32 * ot + li) * 4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(chunk + (((ot * 4 + q) * 64 + h * 32 + li) * 4));
         acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * q + 0], acc[ot], 0, 0, 0);
         acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * q + 1], acc[ot], 0, 0, 0);
         acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[4 * q + 2], acc[ot], 0, 0, 0);
@@ -90,23 +46,6 @@ __device__ __forceinline__ void mm_chunk(f32x16 (&acc)[NT], const f32x16& b, con
   }
 }
 
-// Software-pipelined version for compile-time R (the trunk): hipcc (ROCm 7.2), at the register budget of
-// these kernels, sinks every ds_read_b128 to just before its 4 MFMAs and waits lgkmcnt(0) there (~25 % of the
-// matrix pipe idle).  Here the four A-fragment reads of tile ot+1 are issued (inline asm, immediate offsets
-// from one base VGPR) BEFORE the 16 MFMAs of tile ot, and each tile waits with a counted lgkmcnt(4) whose
-// "+v" operands tie the fragments to the wait (cdna_hip_programming.md 5.7 item 1, form ii).  Counts stay
-// conservative if the compiler has LDS/SMEM operations of its own in flight (LDS returns in order).
-template <int IMM>
-__device__ __forceinline__ void ds_read16(f32x4& d, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
-}
-template <int R, int OT>
-__device__ __forceinline__ void read_tile(f32x4 (&a)[4], uint32_t base) {
-  ds_read16<(0 * 2 * R + 32 * OT) * 16>(a[0], base);
-  ds_read16<(1 * 2 * R + 32 * OT) * 16>(a[1], base);
-  ds_read16<(2 * 2 * R + 32 * OT) * 16>(a[2], base);
-  ds_read16<(3 * 2 * R + 32 * OT) * 16>(a[3], base);
-}
 __device__ __forceinline__ void mfma16(f32x16& acc, const f32x4 (&a)[4], const f32x16& b) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -116,105 +55,140 @@ __device__ __forceinline__ void mfma16(f32x16& acc, const f32x4 (&a)[4], const f
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][3], b[4 * q + 3], acc, 0, 0, 0);
   }
 }
-// Two output tiles per step with their MFMAs interleaved (two independent accumulator chains), fragments of
-// the next pair prefetched: [reads pair p+1] [wait pair p] [32 MFMAs alternating acc[2p], acc[2p+1]].
-__device__ __forceinline__ void mfma16x2(f32x16& c0, f32x16& c1, const f32x4 (&a0)[4], const f32x4 (&a1)[4],
-                                         const f32x16& b) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q][j], b[4 * q + j], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q][j], b[4 * q + j], c1, 0, 0, 0);
-    }
-  }
-}
-template <int NT, int R, int P>   // P = pair index, NT even
-struct MMPair {
-  static __device__ __forceinline__ void run(f32x16 (&acc)[NT], f32x4 (&c0)[4], f32x4 (&c1)[4], f32x4 (&n0)[4],
-                                             f32x4 (&n1)[4], const f32x16& b, uint32_t base, ChunkPipe& pipe) {
-    if constexpr (2 * P + 2 < NT) {
-      read_tile<R, 2 * P + 2>(n0, base);
-      read_tile<R, 2 * P + 3>(n1, base);
-      asm volatile("s_waitcnt lgkmcnt(8)"
-                   : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]));
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]));
-    }
-    mfma16x2(acc[2 * P], acc[2 * P + 1], c0, c1, b);
-    if constexpr (P == 0) pipe.prefetch();   // DMA of the next chunk issues behind MFMAs already in the pipe
-    if constexpr (2 * P + 2 < NT) MMPair<NT, R, P + 1>::run(acc, n0, n1, c0, c1, b, base, pipe);
-  }
-};
-template <int NT, int R>
-__device__ __forceinline__ void mm_chunk_t(f32x16 (&acc)[NT], const f32x16& b, ChunkPipe& pipe, int li, int h) {
-  const float* chunk = pipe.acquire();
-  const uint32_t base =
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)chunk + (uint32_t)((h * R + li) * 16);
-  if constexpr (NT == 1) {
-    f32x4 a0[4];
-    read_tile<R, 0>(a0, base);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]));
-    mfma16(acc[0], a0, b);
-    pipe.prefetch();
-  } else {
-    f32x4 a0[4], a1[4], n0[4], n1[4];
-    read_tile<R, 0>(a0, base);
-    read_tile<R, 1>(a1, base);
-    MMPair<NT, R, 0>::run(acc, a0, a1, n0, n1, b, base, pipe);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Direct-from-L2 variant (fp32 only): every wave reads its A fragments straight from the packed weight stream
 // in global memory (16 B per lane, 1 KiB per wave-instruction, the same image as the LDS chunk) -- no LDS, no
 // workgroup barrier, waves never wait for each other.  At the fp32 MFMA rate a wave needs one 1-KiB fragment
 // load per 256 cycles: 16 B/clk per CU, ~10 TB/s chip-wide against ~34 TB/s of L2 bandwidth, with the 2.1 MB
-// of weights resident in every XCD's 4 MiB L2.  Fragments are fetched two tiles (2048 MFMA-cycles) ahead.
+// of weights resident in every XCD's 4 MiB L2.
 // (The bf16 path cannot do this: 16x the MFMA rate would need 16x the L2 bandwidth -- it keeps the LDS ring.)
-// One LAYER-part = KT chunks x NT tiles, walked as a flat tile stream T = kt*NT + ot with three rotating
-// fragment sets (tile T computing, T+1 and T+2 in flight).  bt[kt] is the B operand of chunk kt.
-// The loads are inline asm (SGPR base + 32-bit lane offset) with hand-counted vmcnt waits, because hipcc
-// (ROCm 7.2) at this register budget sinks ordinary loads to just before their use and waits vmcnt(0) there.
-// vmcnt retires in issue order, so operations of the compiler's own (bias loads, activation stores) that
-// are in flight can only make these counted waits stricter, never too weak.
-__device__ __forceinline__ void gload16(f32x4& d, const float* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase));
-}
-template <int R, int NT, int T>
+//
+// The packed stream of a network is ONE flat sequence of 32x32 weight tiles (chunk kt, output tile ot ->
+// tile index T = kt*NT + ot, all chunks of the trunk have the same R), so the fragment prefetch runs
+// CONTINUOUSLY across layer boundaries: a ring of NB fragment sets lives in the kernel, step T computes tile T
+// from set T % NB while tiles T+1 .. T+NB-1 are in flight, and the last NB-1 steps of a layer already fetch the
+// first tiles of the next layer (the stream allocation is padded by one chunk so the prefetch past the very
+// end stays in bounds).  Every layer part has a tile count that is a multiple of NB, so the ring position is
+// the same at every call.  Loads are only ever IN FLIGHT inside a part (pure MFMA + asm code): the compiler
+// does not know that the destination registers of an asm load are busy, so at every part boundary the ring is
+// landed (land_frags) before compiler-scheduled code runs; scripts/check_inflight.py verifies on the final ISA
+// that no instruction touches a register with a load outstanding.
+//
+// The loads (and the interleaved activation stores of the training kernels, "side" operations) are inline asm
+// with hand-counted s_waitcnt vmcnt(N): hipcc (ROCm 7.2) at this register budget sinks ordinary loads to just
+// before their use and waits vmcnt(0) there.  vmcnt retires in issue order on gfx9, so VMEM operations the
+// kernel does NOT count (the compiler's own loads/stores, side operations of the previous call) can only make
+// a counted wait stricter, never too weak; every operation that IS counted is an asm volatile statement and
+// therefore stays in program order.
+//
+// HAZARD NOTE: "VALU writes SGPR -> VMEM reads that SGPR" needs 5 wait states on gfx9 (CDNA ISA, manually
+// inserted wait states).  hipcc inserts them for its own instructions but does not look inside inline asm, and
+// it does reload spilled SGPR bases with v_readlane right in front of an asm statement -- so every asm
+// statement here that reads an SGPR address starts with s_nop 4 (hidden in the shadow of the running MFMA).
+template <int T>   // tile T of the part that starts at base: 4 KiB at base + T*4 KiB, fragment q at +q KiB
 __device__ __forceinline__ void gload_tile(f32x4 (&a)[4], const float* base, uint32_t voff) {
-  constexpr int kt = T / NT, ot = T % NT;
-  gload16(a[0], base + kt * 32 * R + (0 * 2 * R + 32 * ot) * 4, voff);
-  gload16(a[1], base + kt * 32 * R + (1 * 2 * R + 32 * ot) * 4, voff);
-  gload16(a[2], base + kt * 32 * R + (2 * 2 * R + 32 * ot) * 4, voff);
-  gload16(a[3], base + kt * 32 * R + (3 * 2 * R + 32 * ot) * 4, voff);
+  asm volatile(
+      "s_nop 4\n\t"
+      "global_load_dwordx4 %0, %4, %5\n\t"
+      "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+      "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+      "global_load_dwordx4 %3, %4, %5 offset:3072"
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+      : "v"(voff), "s"(base + T * 1024));
 }
-template <int NT, int R, int KT, int T>
-struct LStep {
-  static __device__ __forceinline__ void run(f32x16 (&acc)[NT], const f32x16 (&bt)[KT], f32x4 (&f0)[4], f32x4 (&f1)[4],
-                                             f32x4 (&f2)[4], const float* base, uint32_t voff) {
-    constexpr int total = KT * NT;
-    if constexpr (T + 2 < total) {
-      gload_tile<R, NT, T + 2>(f2, base, voff);
-      asm volatile("s_waitcnt vmcnt(8)" : "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]));
-    } else if constexpr (T + 1 < total) {
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]));
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]));
+__device__ __forceinline__ void gload4u(uint32_t& d, const uint32_t* sbase, uint32_t voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void gstore4(float* sbase, uint32_t voff, float v) {
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(sbase));
+}
+constexpr int kNB = 4;   // fragment ring: 1 computing + 3 tiles (768 MFMA-cycles) in flight
+
+// side operations: ops(T) = number of VMEM instructions issue<T>() emits (exact, compile time)
+struct NoSide {
+  static constexpr int ops(int) { return 0; }
+  template <int T> __device__ __forceinline__ void issue() const {}
+};
+// spreads the stores of the NSRC*16 registers of src (feature-major rows of dst) evenly over TOTAL steps
+template <int NSRC, int TOTAL>
+struct StoreSide {
+  static constexpr int N = NSRC * 16;
+  static constexpr int PER = (N + TOTAL - 1) / TOTAL;
+  const f32x16* src;
+  float* dst;
+  int64_t Mp;
+  uint32_t voff;
+  static constexpr int ops(int T) { return N - T * PER <= 0 ? 0 : (N - T * PER < PER ? N - T * PER : PER); }
+  template <int T> __device__ __forceinline__ void issue() const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = T * PER + i;
+      if (idx < N) gstore4(dst + (int64_t)(32 * (idx / 16) + ((idx % 16) & 3) + 8 * ((idx % 16) >> 2)) * Mp, voff, src[idx / 16][idx % 16]);
     }
-    mfma16(acc[T % NT], f0, bt[T / NT]);
-    if constexpr (T + 1 < total) LStep<NT, R, KT, T + 1>::run(acc, bt, f1, f2, f0, base, voff);
   }
 };
-// acc[ot] += sum_kt W[:, chunk kt] . bt[kt];  base -> first chunk (global memory, packed image).
-template <int NT, int R, int KT>
-__device__ __forceinline__ void mm_layer_g(f32x16 (&acc)[NT], const f32x16 (&bt)[KT], const float* base, int li, int h) {
-  const uint32_t voff = (uint32_t)((h * R + li) * 16);
-  f32x4 f0[4], f1[4], f2[4];
-  gload_tile<R, NT, 0>(f0, base, voff);
-  if constexpr (KT * NT > 1) gload_tile<R, NT, 1>(f1, base, voff);
-  LStep<NT, R, KT, 0>::run(acc, bt, f0, f1, f2, base, voff);
+// all NT*16 rows of src at once (SGPR row base + 32-bit lane offset; the counted waits after it only get stricter)
+template <int NT>
+__device__ __forceinline__ void store_tiles(float* dst, const f32x16* src, int nt, int64_t Mp, uint32_t voff) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gstore4(dst + (int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp, voff, src[t][r]);
+    }
+  }
+}
+template <class Side>
+constexpr int side_ops_sum(int first, int last) {
+  int n = 0;
+  for (int k = first < 0 ? 0 : first; k <= last; ++k) n += Side::ops(k);
+  return n;
+}
+template <int CNT>
+__device__ __forceinline__ void wait_frag(f32x4 (&a)[4]) {
+  static_assert(CNT >= 0 && CNT < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(CNT));
+}
+// every ring register has landed after this (it also orders the ring against whatever the compiler does next)
+__device__ __forceinline__ void land_frags(f32x4 (&f)[kNB][4]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[0][3]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]),
+                 "+v"(f[1][3]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[2][2]), "+v"(f[2][3]), "+v"(f[3][0]), "+v"(f[3][1]),
+                 "+v"(f[3][2]), "+v"(f[3][3]));
+  __builtin_amdgcn_sched_barrier(0);   // ... and nothing of what follows may be hoisted into the in-flight window
+}
+template <int NT, int R, int KT, class Side, int T>
+struct LStep {
+  static __device__ __forceinline__ void run(f32x16 (&acc)[NT], const f32x16* bt, f32x4 (&f)[kNB][4], const float* base,
+                                             uint32_t voff, const Side& side) {
+    constexpr int PD = kNB - 1;
+    side.template issue<T>();
+    gload_tile<T + PD>(f[(T + PD) % kNB], base, voff);   // past the end of this part = first tiles of the next
+    // in flight behind tile T's loads: tiles T+1..T+PD and the side operations of steps T-PD+1..T
+    wait_frag<4 * PD + side_ops_sum<Side>(T - PD + 1, T)>(f[T % kNB]);
+    mfma16(acc[T % NT], f[T % kNB], bt[T / NT]);
+    if constexpr (T + 1 < KT * NT) LStep<NT, R, KT, Side, T + 1>::run(acc, bt, f, base, voff, side);
+    // Part boundary: the tiles fetched ahead for the next part were issued 1..3 steps (1024 cycles each) ago and
+    // have all but certainly landed while this step's 16 MFMAs drain, so this wait is nearly free -- and from
+    // here on the ring holds ordinary values the compiler may copy or spill as it likes.
+    else land_frags(f);
+  }
+};
+__device__ __forceinline__ uint32_t frag_voff(int lane) { return (uint32_t)(lane * 16); }
+// first call on a stream: fetch tiles 0..NB-2; must be followed directly by mm_layer_g
+__device__ __forceinline__ void prime_frags(f32x4 (&f)[kNB][4], const float* base, uint32_t voff) {
+  __builtin_amdgcn_sched_barrier(0);   // nothing of the prologue may sink below the first in-flight load
+  gload_tile<0>(f[0], base, voff);
+  gload_tile<1>(f[1], base, voff);
+  gload_tile<2>(f[2], base, voff);
+}
+// acc[ot] += sum_kt W[:, chunk kt] . bt[kt];  base -> first chunk of this part (global memory, packed image);
+// the ring must already hold / be fetching tiles 0..NB-2 of this part (prime_frags or the previous part).
+template <int NT, int R, int KT, class Side>
+__device__ __forceinline__ void mm_layer_g(f32x16 (&acc)[NT], const f32x16* bt, f32x4 (&f)[kNB][4], const float* base,
+                                           uint32_t voff, const Side& side) {
+  static_assert((KT * NT) % kNB == 0, "a layer part must keep the ring position");
+  LStep<NT, R, KT, Side, 0>::run(acc, bt, f, base, voff, side);
 }
 
 // feature row held by register r of tile t in lane-half h

@@ -9,8 +9,9 @@
 //
 // Work decomposition: one workgroup = 4 waves = 128 samples; one wave = 32 samples x all features;
 // 1 wave per SIMD with the 512-register file (accumulators 128 + previous layer 128 + encoding 32).
-// Weights stream through LDS in chunks of 32 input features (see mlp_common.cuh), double buffered with
-// global_load_lds (LDS-DMA).
+// Weights: every wave reads its 32x32 fragments straight from the packed stream in L2 through a ring of
+// prefetched register sets that runs continuously across layers (mlp_common.cuh, "direct-from-L2"); the
+// training variant interleaves the activation stores with those loads.
 #include "mlp_common.cuh"
 
 namespace nh {
@@ -24,6 +25,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
                                                              int want_rgb, ActStore st) {
   constexpr int R = 32 * WT;
   constexpr int HTM = WT >= 2 ? WT / 2 : 1;
+  constexpr bool kFast = WT >= 4;   // continuous fragment ring needs tile counts that are multiples of kNB
+  __shared__ __attribute__((aligned(16))) float sbias[kMaxD * R];   // biases: LDS reads do not touch vmcnt
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
   const int64_t m = (int64_t)blockIdx.x * kTile + wave * 32 + li;
@@ -32,9 +35,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   const int64_t ray = mc / S;
   const float* vp = net.vecpack;
   const int W = net.W, D = net.D;
+  const int64_t Mp = TRAIN ? st.Mpad : 0;
   const uint32_t voff = TRAIN ? lane_off(h, st.Mpad, m) : 0u;
 
   const float* wp = (const float*)net.wpack_fwd;   // packed weight stream, consumed front to back
+  const uint32_t fvoff = frag_voff(lane);
+  f32x4 fr[kNB][4];
+  for (int i = tid; i < D * R; i += 256) sbias[i] = vp[i];
 
   // sample position (raysO.add(raysD.mul(zVals)), nerfBlock.scala:65): separate mul and add
   const float zz = z[mc];
@@ -42,49 +49,72 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   const float py = __fadd_rn(rays_o[ray * 3 + 1], __fmul_rn(rays_d[ray * 3 + 1], zz));
   const float pz = __fadd_rn(rays_o[ray * 3 + 2], __fmul_rn(rays_d[ray * 3 + 2], zz));
 
+  // Rows past M repeat sample M-1 (finite values); their gradients are zero in the backward pass, so the
+  // stored activations of those columns never contribute to a weight gradient.
   f32x16 enc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) enc[t][r] = code_value(px, py, pz, tile_row(t, r, h), net.E);
-  if (TRAIN) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) *row_ptr(st.enc, tile_row_u(t, r), st.Mpad, voff) = valid ? enc[t][r] : 0.f;
-  }
+  __syncthreads();
 
   f32x16 act[WT], acc[WT];
-  // TRAIN: the post-ReLU activations of layer l-1 are stored feature-major right AFTER the first weight chunk
-  // of layer l has been waited for, so the chunk pipeline's vmcnt(0) never sits behind 128 fresh stores.
-  auto store_act = [&](int l_done) {
-    float* dst = st.act + (int64_t)l_done * W * st.Mpad;
-#pragma unroll
-    for (int t = 0; t < WT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) *row_ptr(dst, tile_row_u(t, r), st.Mpad, voff) = valid ? act[t][r] : 0.f;
+  auto store_rows = [&](float* dst, const f32x16* src, int nt) { store_tiles<WT>(dst, src, nt, Mp, voff); };
+  auto store_mask = [&](int slot) {
     uint32_t mw[4];
     relu_mask_words<WT>(act, mw, WT);
 #pragma unroll
-    for (int w = 0; w < (WT + 1) / 2; ++w) *mask_ptr(st.mask, l_done, h, w, st.Mpad, m) = valid ? mw[w] : 0u;
+    for (int w = 0; w < (WT + 1) / 2; ++w) *mask_ptr(st.mask, slot, h, w, st.Mpad, m) = mw[w];
   };
-  for (int l = 0; l < D; ++l) {
-    load_rows<WT>(acc, vp + l * W, WT, W, h);  // accumulator := bias
-    if (l > 0) {
-      if (TRAIN) store_act(l - 1);
-      mm_layer_g<WT, R, WT>(acc, act, wp, li, h);
-      wp += WT * 32 * R;
-    }
-    if (l == 0 || ((net.skip_mask >> (l - 1)) & 1u)) {
-      mm_layer_g<WT, R, 2>(acc, enc, wp, li, h);
-      wp += 2 * 32 * R;
-    }
+
+  auto relu_to_act = [&]() {
 #pragma unroll
     for (int t = 0; t < WT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) act[t][r] = fmaxf(acc[t][r], 0.f);
+  };
+  // layer 0: encoding only.  The fragment ring is primed directly in front of its first part: asm loads are
+  // only ever in flight inside a part (mlp_common.cuh).
+  load_rows<WT>(acc, sbias, WT, W, h);  // accumulator := bias
+  if constexpr (kFast) {
+    prime_frags(fr, wp, fvoff);
+    if constexpr (TRAIN) mm_layer_g<WT, R, 2>(acc, enc, fr, wp, fvoff, StoreSide<2, 2 * WT>{enc, st.enc, Mp, voff});
+    else mm_layer_g<WT, R, 2>(acc, enc, fr, wp, fvoff, NoSide{});
+  } else {
+    if (TRAIN) store_tiles<2>(st.enc, enc, 2, Mp, voff);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) mm_chunk<WT>(acc, enc[kt], wp + kt * 32 * R, R, WT, li, h);
   }
-  if (TRAIN && !want_rgb) store_act(D - 1);
+  wp += 2 * 32 * R;
+  relu_to_act();
+  for (int l = 1; l < D; ++l) {
+    load_rows<WT>(acc, sbias + l * R, WT, W, h);
+    float* dst = TRAIN ? st.act + (int64_t)(l - 1) * W * Mp : nullptr;
+    if (TRAIN) store_mask(l - 1);
+    if constexpr (kFast) {
+      // TRAIN: the post-ReLU activations of layer l-1 (the B operand of this layer) go out two rows per tile
+      // step, between the fragment loads, so the HBM writes overlap the MFMAs of the whole layer
+      if constexpr (TRAIN) mm_layer_g<WT, R, WT>(acc, act, fr, wp, fvoff, StoreSide<WT, WT * WT>{act, dst, Mp, voff});
+      else mm_layer_g<WT, R, WT>(acc, act, fr, wp, fvoff, NoSide{});
+    } else {
+      if (TRAIN) store_rows(dst, act, WT);
+#pragma unroll
+      for (int kt = 0; kt < WT; ++kt) mm_chunk<WT>(acc, act[kt], wp + kt * 32 * R, R, WT, li, h);
+    }
+    wp += WT * 32 * R;
+    if ((net.skip_mask >> (l - 1)) & 1u) {
+      if constexpr (kFast) {
+        mm_layer_g<WT, R, 2>(acc, enc, fr, wp, fvoff, NoSide{});
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) mm_chunk<WT>(acc, enc[kt], wp + kt * 32 * R, R, WT, li, h);
+      }
+      wp += 2 * 32 * R;
+    }
+    relu_to_act();
+  }
+  if (TRAIN) store_mask(D - 1);
+  if (TRAIN && !want_rgb) store_rows(st.act + (int64_t)(D - 1) * W * Mp, act, WT);
 
   // density head (nerfCoreBlock.scala:39-40): dot over this lane's half of the features + the other half
   {
@@ -111,9 +141,22 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   f32x16 hacc[HTM];
   if (net.mode == 1) load_rows<HTM>(hacc, dirfeat + ray * Rh, HT, Rh, h);   // Wd.enc(dir) + bd + bf, per ray
   else load_rows<HTM>(hacc, vp + (D + 1) * W, HT, Rh, h);                   // head bias (zero padded)
-  if (TRAIN) store_act(D - 1);
+  {
+    float* dst = TRAIN ? st.act + (int64_t)(D - 1) * W * Mp : nullptr;
+    if (kFast && HT == HTM) {
+      if constexpr (kFast) {
+        constexpr int RH = 32 * HTM;
+        const uint32_t hvoff = frag_voff(lane);
+        prime_frags(fr, wp, hvoff);
+        if constexpr (TRAIN) mm_layer_g<HTM, RH, WT>(hacc, act, fr, wp, hvoff, StoreSide<WT, WT * HTM>{act, dst, Mp, voff});
+        else mm_layer_g<HTM, RH, WT>(hacc, act, fr, wp, hvoff, NoSide{});
+      }
+    } else {
+      if (TRAIN) store_rows(dst, act, WT);
 #pragma unroll
-  for (int kt = 0; kt < WT; ++kt) mm_chunk<HTM>(hacc, act[kt], wp + kt * 32 * Rh, Rh, HT, li, h);
+      for (int kt = 0; kt < WT; ++kt) mm_chunk<HTM>(hacc, act[kt], wp + kt * 32 * Rh, Rh, HT, li, h);
+    }
+  }
 
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   if (net.mode == 1) {
@@ -125,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
         for (int r = 0; r < 16; ++r) hacc[t][r] = fmaxf(hacc[t][r], 0.f);  // add().relu() (:67)
         if (TRAIN) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) *row_ptr(st.hc, tile_row_u(t, r), st.Mpad, voff) = valid ? hacc[t][r] : 0.f;
+          for (int r = 0; r < 16; ++r) *row_ptr(st.hc, tile_row_u(t, r), st.Mpad, voff) = hacc[t][r];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -146,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
       uint32_t mw[4];
       relu_mask_words<HTM>(hacc, mw, HT);
 #pragma unroll
-      for (int w = 0; w < (HTM + 1) / 2; ++w) *mask_ptr(st.mask, D, h, w, st.Mpad, m) = valid ? mw[w] : 0u;
+      for (int w = 0; w < (HTM + 1) / 2; ++w) *mask_ptr(st.mask, D, h, w, st.Mpad, m) = mw[w];
     }
     if (h == 0) {
       c0 += vp[(D + 5) * W + 1];

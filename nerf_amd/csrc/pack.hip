@@ -14,11 +14,12 @@ __global__ void pack_chunks_kernel(const float* __restrict__ params, const Chunk
   const ChunkDesc d = descs[blockIdx.x];
   const float* src = params + d.src_off;
   const int total = 32 * d.R;
+  // tile-linear image (mlp_common.cuh): e = (((ot*4 + q)*64 + h*32 + li)*4 + j)  <->  row i = 32 ot + li,
+  // k = 8q + 4h + j: one output tile of the chunk = 4 KiB contiguous = four 1-KiB wave loads
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int g = e / (d.R * 4);
-    const int rem = e - g * d.R * 4;
-    const int i = rem >> 2, j = rem & 3;
-    const int k = 4 * g + j;
+    const int j = e & 3, lane = (e >> 2) & 63, q = (e >> 8) & 3, ot = e >> 10;
+    const int i = 32 * ot + (lane & 31);
+    const int k = 8 * q + 4 * (lane >> 5) + j;
     float v = 0.f;
     if (d.c0 >= 0 && k < d.kvalid && i < d.ivalid)
       v = d.transposed ? src[(int64_t)(d.c0 + k) * d.ld + i] : src[(int64_t)i * d.ld + d.c0 + k];
