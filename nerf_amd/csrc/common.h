@@ -57,17 +57,25 @@ struct NetArgs {
 
 inline int64_t vecpack_floats(int D, int W) { return (int64_t)(D + 5) * W + 4; }
 
-// activation store of one training pass over M samples (feature-major: [row][Mpad]), fp32
+// Activation store of one training pass over M samples, fp32.  Every buffer is TILE-MAJOR: samples are grouped
+// in tiles of 32 (one wave of the fused MLP kernels) and a buffer with `rows` feature rows holds
+//     element(row, m) = buf[((m >> 5) * rows + row) * 32 + (m & 31)]
+// so the 32-sample x rows block a wave writes -- and the block the weight-gradient GEMM stages per K-chunk -- is
+// ONE contiguous rows*128-byte piece of HBM (sequential DRAM pages, a handful of TLB entries) instead of
+// `rows` 128-byte pieces megabytes apart.
 struct ActStore {
-  float* enc;    // [64][Mpad]
-  float* act;    // [D][W][Mpad]   post-ReLU outputs of the trunk layers
-  float* hc;     // [HT*32][Mpad]  mode 1: post-ReLU colour hidden layer
-  float* dy;     // [D][W][Mpad]   gradients w.r.t. the pre-activations (written by backward)
-  float* dh;     // [HT*32 + 32][Mpad] head gradients: rows < HT*32 d(head pre-act), row HT*32 = d sigma,
+  float* enc;    // [Mpad/32][64][32]
+  float* act;    // [D] x [Mpad/32][W][32]   post-ReLU outputs of the trunk layers (layer l at act + l*W*Mpad)
+  float* hc;     // [Mpad/32][HT*32][32]  mode 1: post-ReLU colour hidden layer
+  float* dy;     // [D] x [Mpad/32][W][32]   gradients w.r.t. the pre-activations (written by backward)
+  float* dh;     // [Mpad/32][HT*32 + 32][32] head gradients: rows < HT*32 d(head pre-act), row HT*32 = d sigma,
                  //                    rows HT*32+1..+3 = d craw^T (mode 1)
   uint32_t* mask;  // [(D+1)][2 (lane half)][4 words][Mpad] ReLU sign bits of act (slot D: hc): bit 16*(t&1)+r of
                    // word t/2 <-> register r of tile t; lets the backward pass fetch 16 B instead of 512 B per layer
   int64_t Mpad;
 };
+__host__ __device__ inline int64_t tiled_index(int64_t row, int64_t m, int64_t rows) {
+  return ((m >> 5) * rows + row) * 32 + (m & 31);
+}
 
 }  // namespace nh

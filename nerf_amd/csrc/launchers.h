@@ -47,13 +47,13 @@ struct WgradItem {
   const float* B;
   float* dW;
   float* db;
-  int64_t ld;
+  int32_t a_stride, b_stride;   // rows per 32-sample tile of the (tile-major, common.h) buffers A and B live in
   int32_t a_rows, b_rows;
   int32_t ldo, col0;
   int32_t c0, c1;      // slice of the sample axis in 32-sample chunks
 };
 hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, hipStream_t s);
-hipError_t launch_ray_sum(const float* dh, int64_t ld, int rows, int64_t n, int S, float* out, int64_t ldo,
+hipError_t launch_ray_sum(const float* dh, int dh_rows, int rows, int64_t n, int S, float* out, int out_rows,
                           hipStream_t s);
 
 }  // namespace nh

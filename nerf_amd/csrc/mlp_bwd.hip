@@ -23,13 +23,21 @@ struct BwdSide {
   St st;
   const uint32_t* mask_next;   // slot base of layer l-1
   uint32_t* mnext;
+  int64_t Mp;
+  uint32_t mvoff;
   static constexpr int ops(int T) { return St::ops(T) + (T == 0 ? NW : 0); }
   template <int T> __device__ __forceinline__ void issue() const {
     if constexpr (T == 0) {
 #pragma unroll
-      for (int w = 0; w < NW; ++w) gload4u(mnext[w], mask_next + (int64_t)w * st.Mp, st.voff);
+      for (int w = 0; w < NW; ++w) gload4u(mnext[w], mask_next + (int64_t)w * Mp, mvoff);
     }
     st.template issue<T>();
+  }
+  // The mask words were requested at step 0; step kNB-1's counted wait retires them (in order).  Until then they
+  // are named by every wait so the compiler keeps them where the loads will land (it would otherwise park the
+  // "values" in AGPRs right behind the load asm, i.e. copy registers whose data has not arrived yet).
+  template <int T> __device__ __forceinline__ void after_wait() const {
+    if constexpr (T < kNB) asm volatile("" : "+v"(mnext[0]), "+v"(mnext[1]), "+v"(mnext[2]), "+v"(mnext[3]));
   }
 };
 
@@ -50,7 +58,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
   const float* vp = net.vecpack;
   const int W = net.W, D = net.D, HT = net.HT, Rh = 32 * net.HT;
   const int64_t Mp = st.Mpad;
-  const uint32_t voff = lane_off(h, Mp, m);
+  const uint32_t voff = tile_voff(lane);                                        // activation-store lane offset
+  const uint32_t mvoff = mask_voff(h, Mp, m);
+  const int tix = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);   // this wave's 32-sample tile
+  float* const dhb = tile_block(st.dh, tix, Rh + 32);
 
   // backward stream: HT head chunks (Wf^T), then WT chunks per trunk layer D-1 .. 1, all with R rows
   const float* wp = (const float*)net.wpack_bwd;
@@ -106,12 +117,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
   }
   // head gradients go out feature-major: rows < Rh, then d sigma, then d craw^T
   if (h == 0) {
-    st.dh[(int64_t)Rh * Mp + m] = dsig;
-    st.dh[(int64_t)(Rh + 1) * Mp + m] = dc0;
-    st.dh[(int64_t)(Rh + 2) * Mp + m] = dc1;
-    st.dh[(int64_t)(Rh + 3) * Mp + m] = dc2;
+    dhb[(Rh + 0) * 32 + li] = dsig;
+    dhb[(Rh + 1) * 32 + li] = dc0;
+    dhb[(Rh + 2) * 32 + li] = dc1;
+    dhb[(Rh + 3) * 32 + li] = dc2;
   }
-  auto store_dh = [&]() { store_tiles<HTM>(st.dh, dh, HT, Mp, voff); };
+  auto store_dh = [&]() { store_tiles<HTM>(dhb, dh, HT, voff); };
 
   // ---- d feat = w_sigma * d sigma + Wf^T . dh
   f32x16 acc[WT], g[WT];
@@ -131,11 +142,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
     // part, mlp_common.cuh) and then runs through the whole stream.  The head chunks are walked even without a
     // colour gradient (dh = 0 then), which keeps the control flow free of un-primed paths.
     prime_frags(fr, wp, fvoff);
-    mm_layer_g<WT, R, 1>(acc, &dh[0], fr, wp, fvoff, StoreSide<1, WT>{&dh[0], st.dh, Mp, voff});
+    mm_layer_g<WT, R, 1>(acc, &dh[0], fr, wp, fvoff, StoreSide<1, WT>{&dh[0], dhb, voff});
 #pragma unroll
     for (int kt = 1; kt < HTM; ++kt)
       if (kt < HT)
-        mm_layer_g<WT, R, 1>(acc, &dh[kt], fr, wp + kt * 32 * R, fvoff, StoreSide<1, WT>{&dh[kt], st.dh + (int64_t)32 * kt * Mp, Mp, voff});
+        mm_layer_g<WT, R, 1>(acc, &dh[kt], fr, wp + kt * 32 * R, fvoff, StoreSide<1, WT>{&dh[kt], dhb + kt * 1024, voff});
   } else {
     store_dh();
     if (has_rgb) {
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
 #pragma unroll
   for (int w = 0; w < NW; ++w) mcur[w] = *mask_ptr(st.mask, D - 1, h, w, Mp, m);
   for (int l = D - 1; l >= 0; --l) {
-    float* dy = st.dy + (int64_t)l * W * Mp;
+    float* dy = tile_block(st.dy + (int64_t)l * W * Mp, tix, W);
 #pragma unroll
     for (int t = 0; t < WT; ++t)
 #pragma unroll
@@ -164,14 +175,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       if constexpr (kFast) {
-        const BwdSide<WT> side{{g, dy, Mp, voff}, st.mask + (int64_t)((l - 1) * 8) * Mp, mnext};
+        const BwdSide<WT> side{{g, dy, voff}, st.mask + (int64_t)((l - 1) * 8) * Mp, mnext, Mp, mvoff};
         mm_layer_g<WT, R, WT>(acc, g, fr, wp, fvoff, side);
-        // the mask loads were issued at step 0 and retired (in order) by the counted waits of the later steps
-        asm volatile("" : "+v"(mnext[0]), "+v"(mnext[1]), "+v"(mnext[2]), "+v"(mnext[3]));
       } else {
 #pragma unroll
         for (int w = 0; w < NW; ++w) mnext[w] = *mask_ptr(st.mask, l - 1, h, w, Mp, m);
-        store_tiles<WT>(dy, g, WT, Mp, voff);
+        store_tiles<WT>(dy, g, WT, voff);
 #pragma unroll
         for (int kt = 0; kt < WT; ++kt) mm_chunk<WT>(acc, g[kt], wp + kt * 32 * R, R, WT, li, h);
       }
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
 #pragma unroll
       for (int w = 0; w < 4; ++w) mcur[w] = mnext[w];
     } else {
-      store_tiles<WT>(dy, g, WT, Mp, voff);
+      store_tiles<WT>(dy, g, WT, voff);
     }
   }
 }

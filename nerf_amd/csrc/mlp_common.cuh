@@ -99,43 +99,69 @@ __device__ __forceinline__ void gload_tile(f32x4 (&a)[4], const float* base, uin
 __device__ __forceinline__ void gload4u(uint32_t& d, const uint32_t* sbase, uint32_t voff) {
   asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase));
 }
+template <int OFF>   // immediate byte offset, < 4096
 __device__ __forceinline__ void gstore4(float* sbase, uint32_t voff, float v) {
-  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(sbase));
+  static_assert(OFF >= 0 && OFF < 4096, "global immediate offset");
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase), "n"(OFF));
 }
 constexpr int kNB = 4;   // fragment ring: 1 computing + 3 tiles (768 MFMA-cycles) in flight
 
 // side operations: ops(T) = number of VMEM instructions issue<T>() emits (exact, compile time)
+// after_wait<T>() runs right behind step T's counted wait (used to pin registers of side LOADS until they landed)
 struct NoSide {
   static constexpr int ops(int) { return 0; }
   template <int T> __device__ __forceinline__ void issue() const {}
+  template <int T> __device__ __forceinline__ void after_wait() const {}
 };
-// spreads the stores of the NSRC*16 registers of src (feature-major rows of dst) evenly over TOTAL steps
+// Stores into the tile-major activation buffers (common.h): `dst` is the wave's 32-sample block of a buffer
+// (wave-uniform -> SGPR), register r of tile t goes to row 32t + R0(r) (+4 in the upper lane half), i.e. to
+//     dst + t*4096 B + R0(r)*128 B (immediate)  +  voff,   voff = tile_voff(lane) = (128 h + li) * 4
+// -- one SGPR base per 32 rows and no per-row address arithmetic.
+__device__ __forceinline__ uint32_t tile_voff(int lane) { return (uint32_t)((128 * (lane >> 5) + (lane & 31)) * 4); }
+__device__ __forceinline__ float* tile_block(float* buf, int tix, int rows) { return buf + (int64_t)tix * rows * 32; }
+template <int T_, int R_>
+__device__ __forceinline__ void store_reg(float* dst, uint32_t voff, float v) {
+  gstore4<((R_ & 3) + 8 * (R_ >> 2)) * 128>(dst + T_ * 1024, voff, v);
+}
+// spreads the stores of the NSRC*16 registers of src evenly over TOTAL steps
 template <int NSRC, int TOTAL>
 struct StoreSide {
   static constexpr int N = NSRC * 16;
   static constexpr int PER = (N + TOTAL - 1) / TOTAL;
   const f32x16* src;
   float* dst;
-  int64_t Mp;
   uint32_t voff;
   static constexpr int ops(int T) { return N - T * PER <= 0 ? 0 : (N - T * PER < PER ? N - T * PER : PER); }
+  template <int IDX> __device__ __forceinline__ void one() const {
+    if constexpr (IDX < N) store_reg<IDX / 16, IDX % 16>(dst, voff, src[IDX / 16][IDX % 16]);
+  }
+  template <int T> __device__ __forceinline__ void after_wait() const {}
   template <int T> __device__ __forceinline__ void issue() const {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int idx = T * PER + i;
-      if (idx < N) gstore4(dst + (int64_t)(32 * (idx / 16) + ((idx % 16) & 3) + 8 * ((idx % 16) >> 2)) * Mp, voff, src[idx / 16][idx % 16]);
+    static_assert(PER == 1 || PER == 2 || PER == 4 || PER == 8 || PER == 16, "stores per step must be a power of two");
+    one<T * PER + 0>(); if constexpr (PER > 1) one<T * PER + 1>();
+    if constexpr (PER > 2) { one<T * PER + 2>(); one<T * PER + 3>(); }
+    if constexpr (PER > 4) { one<T * PER + 4>(); one<T * PER + 5>(); one<T * PER + 6>(); one<T * PER + 7>(); }
+    if constexpr (PER > 8) {
+      one<T * PER + 8>(); one<T * PER + 9>(); one<T * PER + 10>(); one<T * PER + 11>();
+      one<T * PER + 12>(); one<T * PER + 13>(); one<T * PER + 14>(); one<T * PER + 15>();
     }
   }
 };
-// all NT*16 rows of src at once (SGPR row base + 32-bit lane offset; the counted waits after it only get stricter)
-template <int NT>
-__device__ __forceinline__ void store_tiles(float* dst, const f32x16* src, int nt, int64_t Mp, uint32_t voff) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t < nt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gstore4(dst + (int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp, voff, src[t][r]);
+// all rows of the first nt (<= NT) tiles of src at once
+template <int NT, int T_ = 0>
+__device__ __forceinline__ void store_tiles(float* dst, const f32x16* src, int nt, uint32_t voff) {
+  if constexpr (T_ < NT) {
+    if (T_ < nt) {
+      store_reg<T_, 0>(dst, voff, src[T_][0]);   store_reg<T_, 1>(dst, voff, src[T_][1]);
+      store_reg<T_, 2>(dst, voff, src[T_][2]);   store_reg<T_, 3>(dst, voff, src[T_][3]);
+      store_reg<T_, 4>(dst, voff, src[T_][4]);   store_reg<T_, 5>(dst, voff, src[T_][5]);
+      store_reg<T_, 6>(dst, voff, src[T_][6]);   store_reg<T_, 7>(dst, voff, src[T_][7]);
+      store_reg<T_, 8>(dst, voff, src[T_][8]);   store_reg<T_, 9>(dst, voff, src[T_][9]);
+      store_reg<T_, 10>(dst, voff, src[T_][10]); store_reg<T_, 11>(dst, voff, src[T_][11]);
+      store_reg<T_, 12>(dst, voff, src[T_][12]); store_reg<T_, 13>(dst, voff, src[T_][13]);
+      store_reg<T_, 14>(dst, voff, src[T_][14]); store_reg<T_, 15>(dst, voff, src[T_][15]);
     }
+    store_tiles<NT, T_ + 1>(dst, src, nt, voff);
   }
 }
 template <class Side>
@@ -166,6 +192,7 @@ struct LStep {
     gload_tile<T + PD>(f[(T + PD) % kNB], base, voff);   // past the end of this part = first tiles of the next
     // in flight behind tile T's loads: tiles T+1..T+PD and the side operations of steps T-PD+1..T
     wait_frag<4 * PD + side_ops_sum<Side>(T - PD + 1, T)>(f[T % kNB]);
+    side.template after_wait<T>();
     mfma16(acc[T % NT], f[T % kNB], bt[T / NT]);
     if constexpr (T + 1 < KT * NT) LStep<NT, R, KT, Side, T + 1>::run(acc, bt, f, base, voff, side);
     // Part boundary: the tiles fetched ahead for the next part were issued 1..3 steps (1024 cycles each) ago and
@@ -196,16 +223,8 @@ __device__ __forceinline__ constexpr int tile_row(int t, int r, int h) {
   return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
 
-// Feature-major activation store addressing: element (row, m) of a [rows][Mp] fp32 buffer where
-// row = row_u + 4h (row_u wave-uniform).  Written as (uniform 64-bit base) + (32-bit per-lane byte offset)
-// so the compiler emits SGPR-base global loads/stores instead of one 64-bit VGPR address per row.
-__device__ __forceinline__ uint32_t lane_off(int h, int64_t Mp, int64_t m) { return (uint32_t)((4 * h * Mp + m) * 4); }
-__device__ __forceinline__ float* row_ptr(float* base, int64_t row_u, int64_t Mp, uint32_t voff) {
-  return reinterpret_cast<float*>(reinterpret_cast<char*>(base + row_u * Mp) + voff);
-}
-__device__ __forceinline__ const float* row_ptr(const float* base, int64_t row_u, int64_t Mp, uint32_t voff) {
-  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + row_u * Mp) + voff);
-}
+// byte offset of lane (h, sample m) inside one [4 words][Mp] plane pair of the ReLU mask buffer
+__device__ __forceinline__ uint32_t mask_voff(int h, int64_t Mp, int64_t m) { return (uint32_t)((4 * h * Mp + m) * 4); }
 __device__ __forceinline__ constexpr int tile_row_u(int t, int r) { return 32 * t + (r & 3) + 8 * (r >> 2); }
 
 // ReLU sign bits of NT accumulator tiles, 2 tiles per 32-bit word

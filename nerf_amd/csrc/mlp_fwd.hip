@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   const float* vp = net.vecpack;
   const int W = net.W, D = net.D;
   const int64_t Mp = TRAIN ? st.Mpad : 0;
-  const uint32_t voff = TRAIN ? lane_off(h, st.Mpad, m) : 0u;
+  const uint32_t voff = tile_voff(lane);                                        // activation-store lane offset
+  const int tix = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);   // this wave's 32-sample tile
 
   const float* wp = (const float*)net.wpack_fwd;   // packed weight stream, consumed front to back
   const uint32_t fvoff = frag_voff(lane);
@@ -59,7 +60,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   __syncthreads();
 
   f32x16 act[WT], acc[WT];
-  auto store_rows = [&](float* dst, const f32x16* src, int nt) { store_tiles<WT>(dst, src, nt, Mp, voff); };
   auto store_mask = [&](int slot) {
     uint32_t mw[4];
     relu_mask_words<WT>(act, mw, WT);
@@ -78,10 +78,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   load_rows<WT>(acc, sbias, WT, W, h);  // accumulator := bias
   if constexpr (kFast) {
     prime_frags(fr, wp, fvoff);
-    if constexpr (TRAIN) mm_layer_g<WT, R, 2>(acc, enc, fr, wp, fvoff, StoreSide<2, 2 * WT>{enc, st.enc, Mp, voff});
+    if constexpr (TRAIN) mm_layer_g<WT, R, 2>(acc, enc, fr, wp, fvoff, StoreSide<2, 2 * WT>{enc, tile_block(st.enc, tix, 64), voff});
     else mm_layer_g<WT, R, 2>(acc, enc, fr, wp, fvoff, NoSide{});
   } else {
-    if (TRAIN) store_tiles<2>(st.enc, enc, 2, Mp, voff);
+    if (TRAIN) store_tiles<2>(tile_block(st.enc, tix, 64), enc, 2, voff);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) mm_chunk<WT>(acc, enc[kt], wp + kt * 32 * R, R, WT, li, h);
   }
@@ -89,15 +89,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   relu_to_act();
   for (int l = 1; l < D; ++l) {
     load_rows<WT>(acc, sbias + l * R, WT, W, h);
-    float* dst = TRAIN ? st.act + (int64_t)(l - 1) * W * Mp : nullptr;
+    float* dst = TRAIN ? tile_block(st.act + (int64_t)(l - 1) * W * Mp, tix, W) : nullptr;
     if (TRAIN) store_mask(l - 1);
     if constexpr (kFast) {
       // TRAIN: the post-ReLU activations of layer l-1 (the B operand of this layer) go out two rows per tile
       // step, between the fragment loads, so the HBM writes overlap the MFMAs of the whole layer
-      if constexpr (TRAIN) mm_layer_g<WT, R, WT>(acc, act, fr, wp, fvoff, StoreSide<WT, WT * WT>{act, dst, Mp, voff});
+      if constexpr (TRAIN) mm_layer_g<WT, R, WT>(acc, act, fr, wp, fvoff, StoreSide<WT, WT * WT>{act, dst, voff});
       else mm_layer_g<WT, R, WT>(acc, act, fr, wp, fvoff, NoSide{});
     } else {
-      if (TRAIN) store_rows(dst, act, WT);
+      if (TRAIN) store_tiles<WT>(dst, act, WT, voff);
 #pragma unroll
       for (int kt = 0; kt < WT; ++kt) mm_chunk<WT>(acc, act[kt], wp + kt * 32 * R, R, WT, li, h);
     }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
     relu_to_act();
   }
   if (TRAIN) store_mask(D - 1);
-  if (TRAIN && !want_rgb) store_rows(st.act + (int64_t)(D - 1) * W * Mp, act, WT);
+  if (TRAIN && !want_rgb) store_tiles<WT>(tile_block(st.act + (int64_t)(D - 1) * W * Mp, tix, W), act, WT, voff);
 
   // density head (nerfCoreBlock.scala:39-40): dot over this lane's half of the features + the other half
   {
@@ -142,17 +142,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   if (net.mode == 1) load_rows<HTM>(hacc, dirfeat + ray * Rh, HT, Rh, h);   // Wd.enc(dir) + bd + bf, per ray
   else load_rows<HTM>(hacc, vp + (D + 1) * W, HT, Rh, h);                   // head bias (zero padded)
   {
-    float* dst = TRAIN ? st.act + (int64_t)(D - 1) * W * Mp : nullptr;
+    float* dst = TRAIN ? tile_block(st.act + (int64_t)(D - 1) * W * Mp, tix, W) : nullptr;
     if (kFast && HT == HTM) {
       if constexpr (kFast) {
         constexpr int RH = 32 * HTM;
         const uint32_t hvoff = frag_voff(lane);
         prime_frags(fr, wp, hvoff);
-        if constexpr (TRAIN) mm_layer_g<HTM, RH, WT>(hacc, act, fr, wp, hvoff, StoreSide<WT, WT * HTM>{act, dst, Mp, voff});
+        if constexpr (TRAIN) mm_layer_g<HTM, RH, WT>(hacc, act, fr, wp, hvoff, StoreSide<WT, WT * HTM>{act, dst, voff});
         else mm_layer_g<HTM, RH, WT>(hacc, act, fr, wp, hvoff, NoSide{});
       }
     } else {
-      if (TRAIN) store_rows(dst, act, WT);
+      if (TRAIN) store_tiles<WT>(dst, act, WT, voff);
 #pragma unroll
       for (int kt = 0; kt < WT; ++kt) mm_chunk<HTM>(hacc, act[kt], wp + kt * 32 * Rh, Rh, HT, li, h);
     }
@@ -166,10 +166,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
       if (t < HT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[t][r] = fmaxf(hacc[t][r], 0.f);  // add().relu() (:67)
-        if (TRAIN) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) *row_ptr(st.hc, tile_row_u(t, r), st.Mpad, voff) = hacc[t][r];
-        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = 32 * t + 8 * q + 4 * h;
@@ -186,6 +182,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
       }
     }
     if (TRAIN) {
+      store_tiles<HTM>(tile_block(st.hc, tix, Rh), hacc, HT, voff);
       uint32_t mw[4];
       relu_mask_words<HTM>(hacc, mw, HT);
 #pragma unroll

@@ -66,7 +66,7 @@ __device__ __forceinline__ float dir_code(const float* v, int e) {  // positionC
 
 // mode 1: dirvec[ray][Rh] = Wd . positionCode(viewdir, dirL) + bd + bf  (the Linear(W/2) on enc(dir) of
 // nerfCoreBlock.scala:72-74 plus both biases of the add at :67); rows >= H2 are 0.
-// Optionally writes enc(dir)^T [32][Bpad] for the weight gradient.
+// Optionally writes enc(dir)^T, tile-major [Bpad/32][32][32] (common.h), for the weight gradient.
 __global__ __launch_bounds__(256) void dir_branch_kernel(const float* __restrict__ params, NetLayout L, int Rh,
                                                          const float* __restrict__ viewdir, int64_t n,
                                                          float* __restrict__ dirvec, float* __restrict__ encT,
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void dir_branch_kernel(const float* __restrict
     float v = 0.f;
     if (ray < n && e < Ed) v = dir_code(viewdir + ray * 3, e);
     enc[r][e] = v;
-    if (encT && ray < n) encT[(int64_t)e * Bpad + ray] = v;
+    if (encT && ray < n) encT[tiled_index(e, ray, 32)] = v;
   }
   __syncthreads();
   const int r = threadIdx.x / Rh, j = threadIdx.x - r * Rh;

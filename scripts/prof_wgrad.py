@@ -1,0 +1,19 @@
+"""rocprofv3 driver: two fp32 train steps of the full network (kernels of interest: wgrad, mlp_bwd, mlp_fwd)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import helpers as H
+from nerf_amd import NerfBlock, NerfConfig
+c = dict(H.CONFIGS["full"], dtype="f32")
+nT = 4096
+tr = NerfBlock(NerfConfig.from_dict(dict(c, maxRays=nT)))
+tr.init_params(1)
+ro, rd, b, lab = H.make_rays(nT, 1)
+dev = lambda a: torch.from_numpy(a).cuda()
+o, d, bb, l = dev(ro), dev(rd), dev(b), dev(lab)
+torch.cuda.synchronize()
+for _ in range(2):
+    tr.train_step_dev(o, d, bb, d, l, nT)
+tr.synchronize()
+print("done")
