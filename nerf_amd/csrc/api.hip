@@ -5,8 +5,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <queue>
 #include <vector>
 
 #include "launchers.h"
@@ -69,8 +71,12 @@ struct nerfhip {
   double* d_loss = nullptr;  // [2]
   bool train_ws = false;
   nh::WgradItem* d_items = nullptr;
+  int32_t* d_items_first = nullptr;   // [n workgroups + 1] first work entry of every persistent workgroup
+  std::vector<int32_t> items_first;
   std::vector<nh::WgradItem> items;
-  int wg_chunks = 192;   // 32-sample chunks per weight-gradient work entry
+  int64_t items_nr = -1; // ray count the work list in d_items was built for
+  double items_flop = 0;
+  int n_cu = 256;
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -402,6 +408,8 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
   nerfhip* h = new nerfhip();
   h->cfg = c;
   if (hipSetDevice(c.device) != hipSuccess) { delete h; return fail(nullptr, NERFHIP_E_HIP, "hipSetDevice failed"); }
+  { int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && ncu > 0) h->n_cu = ncu; }
   h->nnets = c.use_hierarchical ? 2 : 1;
   h->N = c.n_samples;
   h->NI = c.use_hierarchical ? c.n_importance : 0;
@@ -472,7 +480,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   hipSetDevice(h->cfg.device);
   if (h->stream) hipStreamSynchronize(h->stream);
   auto fr = [](void* p) { if (p) hipFree(p); };
-  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items);
+  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
     fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd);

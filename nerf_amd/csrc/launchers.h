@@ -51,8 +51,10 @@ struct WgradItem {
   int32_t a_rows, b_rows;
   int32_t ldo, col0;
   int32_t c0, c1;      // slice of the sample axis in 32-sample chunks
+  int32_t wb_n;        // waves along B (1, 2 or 4); waves along A = 4 / wb_n
+  int32_t shape;       // tiles per wave: AT * 16 + BT, each in {1, 2, 4}
 };
-hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, hipStream_t s);
+hipError_t launch_wgrad_f32(const WgradItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s);
 hipError_t launch_ray_sum(const float* dh, int dh_rows, int rows, int64_t n, int S, float* out, int out_rows,
                           hipStream_t s);
 

@@ -6,12 +6,14 @@
 // output) and one K-chunk of an operand is a single contiguous rows*128-byte block of HBM.  At the fp32 MFMA
 // peak this kernel has to stream 64 flop/byte = 2.45 TB/s of operands, so the access pattern matters.
 // One workgroup (4 waves, 1 per SIMD, 512-register file) owns a whole <=256x256 output tile in
-// accumulators (each wave 128x128 = 4x4 MFMA tiles = 256 registers) and walks a slice of the sample axis
+// accumulators (a wave holds up to 4x4 MFMA tiles = 256 registers; the 4 waves are arranged 2x2, 1x4 or 4x1
+// over the output by the host so that narrow outputs -- the 63-row encoding, the 128-row head -- still use
+// all four SIMDs) and walks a slice of the sample axis
 // in chunks of 32 samples staged by LDS-DMA into an XOR-swizzled image; slices of the sample axis are
 // combined with fp32 atomics into the (pre-zeroed) canonical gradient buffer: per 256x256 layer that is
 // (#slices) x 256 KiB of atomic traffic, two to three orders of magnitude below the operand stream.
-// The host cuts every (layer, network) into work entries of at most `wg_chunks` chunks so all workgroups carry
-// about the same work (the coarse network has 1/3 of the fine one's samples) and launches the longest first.
+// The kernel is persistent: n_cu workgroups, each working through an equal share of all products' sample axes
+// (host: train_impl.inc), so there is no tail and only ~n_cu + #products accumulator flushes per step.
 // The k order inside an 8-sample group is permuted (lane half h takes samples 4h..4h+3) identically for A
 // and B, so one 16-byte LDS read feeds four MFMAs.
 #include "mlp_common.cuh"
@@ -22,6 +24,7 @@ namespace nh {
 
 constexpr int kWgRows = 256;                 // max rows per operand tile
 constexpr int kWgChunkFloats = kWgRows * 32; // one operand, one chunk: 256 rows x 32 samples
+constexpr int kWgBufBytes = 2 * kWgChunkFloats * 4;   // one buffer = A chunk | B chunk = 64 KiB
 
 // LDS image of one operand chunk: [row][8 x 16-byte slots], slot s of row r holds samples
 // 4*(s ^ swz(r)) .. +3 with swz(r) = (r >> 1) & 7  (conflict-free ds_read_b128 across 16 rows)
@@ -38,99 +41,162 @@ __device__ __forceinline__ void stage_operand(const float* g, int rows, float* l
   }
 }
 
-__global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __restrict__ items) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers x (A chunk | B chunk)
-  const WgradItem it = items[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
-  const int c0 = it.c0, c1 = it.c1;   // this work entry's slice of the sample axis, in 32-sample chunks
-  if (c0 >= c1) return;
-  const int wa = wave >> 1, wb = wave & 1;          // this wave: A rows [128 wa, +128) x B rows [128 wb, +128)
-  const int a_tiles = min(4, max(0, (it.a_rows - 128 * wa + 31) / 32));
-  const int b_tiles = min(4, max(0, (it.b_rows - 128 * wb + 31) / 32));
+// Fragment reads are inline asm with counted lgkmcnt waits (the compiler would otherwise put every
+// ds_read_b128 right in front of its MFMAs behind an lgkmcnt(0)): the AT+BT reads of k-group g+1 are issued
+// before the AT*BT*4 MFMAs of group g.  LDS operations retire in order.
+template <int IMM>
+__device__ __forceinline__ void lds_read16(f32x4& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+template <int NT>
+__device__ __forceinline__ void read_frags(f32x4 (&f)[NT], uint32_t addr) {   // tile i = rows +32i = +4096 B
+  lds_read16<0>(f[0], addr);
+  if constexpr (NT > 1) lds_read16<4096>(f[1], addr);
+  if constexpr (NT > 2) { lds_read16<8192>(f[2], addr); lds_read16<12288>(f[3], addr); }
+}
+template <int NT>
+__device__ __forceinline__ void tie_frags(f32x4 (&f)[NT]) {
+  asm volatile("" : "+v"(f[0]));
+  if constexpr (NT > 1) asm volatile("" : "+v"(f[1]));
+  if constexpr (NT > 2) { asm volatile("" : "+v"(f[2])); asm volatile("" : "+v"(f[3])); }
+}
+// fp32 add without return on a GLOBAL pointer (a generic pointer gives flat_atomic_add, which also ties up lgkmcnt)
+__device__ __forceinline__ void gatomic_add(float* p, float v) {
+  __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N)); }
 
-  f32x16 acc[4][4];
+// One workgroup = one work entry; wave (wa, wb) owns A tiles [AT*wa, +AT) x B tiles [BT*wb, +BT).
+template <int AT, int BT>
+__device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int wave, int lane) {
+  static_assert((AT == 1 || AT == 2 || AT == 4) && (BT == 1 || BT == 2 || BT == 4), "");
+  const int li = lane & 31, h = lane >> 5;
+  const int wa = wave / it.wb_n, wb = wave - wa * it.wb_n;
+  const int a_row0 = 32 * AT * wa, b_row0 = 32 * BT * wb;
+  const int c0 = it.c0, c1 = it.c1;   // this work entry's slice of the sample axis, in 32-sample chunks
+
+  f32x16 acc[AT][BT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < AT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < BT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // bias gradient = row sums of A: the waves with wb == 0 add up the A fragments they hold anyway (lane half h
   // has 4 of every 8 samples of row 32i + li; the halves are combined at the end) -- no extra LDS traffic
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  float bs[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) bs[i] = 0.f;
   const bool do_bias = it.db != nullptr && wb == 0;
 
-  // buffer b: A chunk at smem + 2b*chunk, B chunk at smem + (2b+1)*chunk
+  // per-lane LDS byte addresses: row (row0 + li) of the A / B image + swizzled slot of k-group g
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem;
+  const uint32_t sw = (uint32_t)((li >> 1) & 7);
+  const uint32_t laneA = lds0 + (uint32_t)(a_row0 + li) * 128u;
+  const uint32_t laneB = lds0 + (uint32_t)kWgChunkFloats * 4u + (uint32_t)(b_row0 + li) * 128u;
+  uint32_t xoff[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xoff[g] = 16u * ((uint32_t)(2 * g + h) ^ sw);
+
   const int64_t a_step = (int64_t)it.a_stride * 32, b_step = (int64_t)it.b_stride * 32;   // floats per chunk
-  stage_operand(it.A + c0 * a_step, it.a_rows, smem, wave, lane);
-  stage_operand(it.B + c0 * b_step, it.b_rows, smem + kWgChunkFloats, wave, lane);
-  for (int c = c0; c < c1; ++c) {
-    const int cur = (c - c0) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c + 1 < c1) {
-      float* nb = smem + (cur ^ 1) * 2 * kWgChunkFloats;
-      stage_operand(it.A + (c + 1) * a_step, it.a_rows, nb, wave, lane);
-      stage_operand(it.B + (c + 1) * b_step, it.b_rows, nb + kWgChunkFloats, wave, lane);
+  auto stage = [&](int c, int buf) {
+    float* dst = smem + buf * 2 * kWgChunkFloats;
+    stage_operand(it.A + c * a_step, it.a_rows, dst, wave, lane);
+    stage_operand(it.B + c * b_step, it.b_rows, dst + kWgChunkFloats, wave, lane);
+  };
+  stage(c0, 0);
+  if (c0 + 1 < c1) stage(c0 + 1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 fa[2][AT], fb[2][BT];
+  auto reads = [&](int set, uint32_t bufoff, int g) {
+    if (set == 0) { read_frags<AT>(fa[0], laneA + bufoff + xoff[g]); read_frags<BT>(fb[0], laneB + bufoff + xoff[g]); }
+    else          { read_frags<AT>(fa[1], laneA + bufoff + xoff[g]); read_frags<BT>(fb[1], laneB + bufoff + xoff[g]); }
+  };
+  auto mfmas = [&](f32x4 (&a)[AT], f32x4 (&b)[BT]) {
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < AT; ++i) bs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
     }
-    const float* As = smem + cur * 2 * kWgChunkFloats;
-    const float* Bs = As + kWgChunkFloats;
 #pragma unroll
-    for (int g8 = 0; g8 < 4; ++g8) {      // 8-sample group: lane half h takes samples 8 g8 + 4h .. +3
-      const int slot = 2 * g8 + h;
-      f32x4 af[4], bf[4];
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra = 128 * wa + 32 * i + li;
-        af[i] = *reinterpret_cast<const f32x4*>(As + ra * 32 + 4 * (slot ^ ((ra >> 1) & 7)));
-        const int rb = 128 * wb + 32 * i + li;
-        bf[i] = *reinterpret_cast<const f32x4*>(Bs + rb * 32 + 4 * (slot ^ ((rb >> 1) & 7)));
-      }
-      if (do_bias) {
+      for (int i = 0; i < AT; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bs[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < a_tiles) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < b_tiles) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][2], bf[j][2], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][3], bf[j][3], acc[i][j], 0, 0, 0);
-            }
-          }
-        }
-      }
+        for (int j = 0; j < BT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
+  };
+  // One chunk: k-groups 0..3.  With a chunk to follow, the hand-over to its buffer (DMA landed for everyone,
+  // request of the chunk after it, first fragment reads) sits between the last wait and the last MFMAs.
+  auto chunk = [&](int c, bool has_next) {
+    const uint32_t cur = (uint32_t)((c - c0) & 1) * (uint32_t)kWgBufBytes;
+    reads(1, cur, 1);
+    wait_lgkm<AT + BT>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]);
+    mfmas(fa[0], fb[0]);
+    reads(0, cur, 2);
+    wait_lgkm<AT + BT>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]);
+    mfmas(fa[1], fb[1]);
+    reads(1, cur, 3);
+    wait_lgkm<AT + BT>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]);
+    mfmas(fa[0], fb[0]);
+    wait_lgkm<0>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]);
+    if (has_next) {
+      // every wave is done READING this buffer; chunk c+1 (requested one chunk ago) must have landed for all
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (c + 2 < c1) stage(c + 2, (c - c0) & 1);
+      reads(0, cur ^ (uint32_t)kWgBufBytes, 0);
     }
-  }
+    mfmas(fa[1], fb[1]);   // ... all of it behind these MFMAs
+  };
+  reads(0, 0u, 0);
+  for (int c = c0; c < c1 - 1; ++c) chunk(c, true);
+  chunk(c1 - 1, false);   // peeled: no fragment read is in flight when the loop is left
   // combine the sample-axis slices: fp32 atomics, 128 contiguous bytes per lane half per instruction
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < a_tiles) {
+  for (int i = 0; i < AT; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < b_tiles) {
-          const int col = 128 * wb + 32 * j + li;
+    for (int j = 0; j < BT; ++j) {
+      const int col = b_row0 + 32 * j + li;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = 128 * wa + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < it.a_rows && col < it.b_rows)
-              atomicAdd(it.dW + (int64_t)row * it.ldo + it.col0 + col, acc[i][j][r]);
-          }
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int row = a_row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < it.a_rows && col < it.b_rows) gatomic_add(it.dW + (int64_t)row * it.ldo + it.col0 + col, acc[i][j][r]);
       }
     }
   }
   if (do_bias) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AT; ++i) {
       const float v = bs[i] + __shfl_xor(bs[i], 32);
-      const int row = 128 * wa + 32 * i + li;
-      if (h == 0 && row < it.a_rows) atomicAdd(it.db + row, v);
+      const int row = a_row0 + 32 * i + li;
+      if (h == 0 && row < it.a_rows) gatomic_add(it.db + row, v);
     }
+  }
+}
+
+// Persistent workgroup b works through the entries first[b] .. first[b+1]-1 (host: train_impl.inc).
+__global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __restrict__ items,
+                                                           const int32_t* __restrict__ first) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers x (A chunk | B chunk)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int e0 = first[blockIdx.x], e1 = first[blockIdx.x + 1];
+  for (int e = e0; e < e1; ++e) {
+    const WgradItem it = items[e];
+    if (it.c0 >= it.c1) continue;
+    switch (it.shape) {   // (tiles per wave along A) * 16 + (tiles per wave along B), chosen by the host
+      case 0x44: wgrad_body<4, 4>(it, smem, wave, lane); break;
+      case 0x42: wgrad_body<4, 2>(it, smem, wave, lane); break;
+      case 0x41: wgrad_body<4, 1>(it, smem, wave, lane); break;
+      case 0x24: wgrad_body<2, 4>(it, smem, wave, lane); break;
+      case 0x22: wgrad_body<2, 2>(it, smem, wave, lane); break;
+      case 0x21: wgrad_body<2, 1>(it, smem, wave, lane); break;
+      case 0x14: wgrad_body<1, 4>(it, smem, wave, lane); break;
+      case 0x12: wgrad_body<1, 2>(it, smem, wave, lane); break;
+      default:   wgrad_body<1, 1>(it, smem, wave, lane); break;
+    }
+    __syncthreads();   // every wave is done reading the LDS buffers before the next entry stages into them
   }
 }
 
@@ -150,8 +216,8 @@ __global__ __launch_bounds__(256) void ray_sum_kernel(const float* __restrict__ 
   if (lane == 0) out[tiled_index(j, ray, out_rows)] = s;
 }
 
-hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, hipStream_t s) {
-  if (nitems <= 0) return hipSuccess;
+hipError_t launch_wgrad_f32(const WgradItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s) {
+  if (ngroups <= 0) return hipSuccess;
   const size_t lds = (size_t)4 * kWgChunkFloats * sizeof(float);  // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
@@ -159,7 +225,7 @@ hipError_t launch_wgrad_f32(const WgradItem* d_items, int nitems, hipStream_t s)
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(nitems), dim3(256), lds, s, d_items);
+  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(ngroups), dim3(256), lds, s, d_items, d_first);
   return hipGetLastError();
 }
 

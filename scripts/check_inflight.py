@@ -2,7 +2,8 @@
 """Static safety check of the fused MLP kernels' ISA (gfx950).
 
 The kernels issue their weight-fragment loads as inline asm and wait for them with hand-counted
-`s_waitcnt vmcnt(N)` many instructions later (nerf_amd/csrc/mlp_common.cuh).  The compiler does not know
+`s_waitcnt vmcnt(N)` many instructions later (nerf_amd/csrc/mlp_common.cuh); wgrad.hip does the same with LDS
+reads and lgkmcnt.  The compiler does not know
 that the destination VGPRs of such a load are "in flight": if its register allocator copies, spills or
 re-uses one of them before the load has landed, the kernel computes garbage or -- when the register is
 re-used for an address -- faults the GPU.  This tool runs a forward data-flow analysis over the kernel's
@@ -17,9 +18,11 @@ import re
 import sys
 
 VMEM = re.compile(r"^(global_|scratch_|buffer_|flat_)(load|store|atomic)")
+LGKM = re.compile(r"^(ds_|s_load_|s_buffer_load_)")
 RE_RANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
 RE_ONE = re.compile(r"\bv(\d+)\b")
 RE_VMCNT = re.compile(r"vmcnt\((\d+)\)")
+RE_LGKM = re.compile(r"lgkmcnt\((\d+)\)")
 RE_LABEL = re.compile(r"^(\.LBB\d+_\d+):")
 RE_BRANCH = re.compile(r"^s_(c?branch\S*)\s+(\.LBB\d+_\d+)")
 CAP = 64   # vmcnt is a 6-bit counter: operations older than this can only be retired by vmcnt(0)
@@ -71,41 +74,61 @@ def parse(body):
     return blocks
 
 
-def merge(a, b):
+def merge1(a, b):
     """queues are lists oldest..newest of frozensets; align at the newest end, union element-wise"""
-    if a is None:
-        return list(b)
     n = max(len(a), len(b))
     pa = [frozenset()] * (n - len(a)) + a
     pb = [frozenset()] * (n - len(b)) + b
     return [x | y for x, y in zip(pa, pb)]
 
 
-def transfer(block, q, viol):
-    q = list(q)
+def merge(a, b):
+    """state = (vmcnt queue, lgkmcnt queue)"""
+    if a is None:
+        return (list(b[0]), list(b[1]))
+    return (merge1(a[0], b[0]), merge1(a[1], b[1]))
+
+
+def retire(q, n):
+    return (q[len(q) - n:] if n else []) if len(q) > n else q
+
+
+def push(q, dst):
+    q.append(dst)
+    if len(q) > CAP:
+        q[:2] = [q[0] | q[1]]
+
+
+def transfer(block, state, viol):
+    qv, ql = list(state[0]), list(state[1])
     for line_no, c, in_asm in block["ins"]:
         if c.startswith("s_waitcnt"):
             m = RE_VMCNT.search(c)
             if m:
-                n = int(m.group(1))
-                if len(q) > n:
-                    q = q[len(q) - n:] if n else []
+                qv = retire(qv, int(m.group(1)))
+            m = RE_LGKM.search(c)
+            if m:
+                ql = retire(ql, int(m.group(1)))
+            continue
+        if LGKM.match(c) and c.startswith("s_"):
+            push(ql, frozenset())
             continue
         if c.startswith("s_"):
             continue
         used = vregs(c)
         busy = set()
-        for d in q:
+        for d in qv:
+            busy |= d
+        for d in ql:
             busy |= d
         hot = used & busy
         if hot and viol is not None:
             viol[line_no] = (c, sorted(hot))
         if VMEM.match(c):
-            dst = frozenset(vregs(c.split(",")[0])) if (in_asm and "_load_" in c) else frozenset()
-            q.append(dst)
-            if len(q) > CAP:
-                q = [q[0] | q[1]] + q[2:]
-    return q
+            push(qv, frozenset(vregs(c.split(",")[0])) if (in_asm and "_load_" in c and "_lds_" not in c) else frozenset())
+        elif LGKM.match(c):
+            push(ql, frozenset(vregs(c.split(",")[0])) if (in_asm and c.startswith("ds_read")) else frozenset())
+    return (qv, ql)
 
 
 def check_kernel(lines, start):
@@ -113,7 +136,7 @@ def check_kernel(lines, start):
     body = lines[start + 1:end + 1]
     blocks = parse(body)
     state_in = [None] * len(blocks)
-    state_in[0] = []
+    state_in[0] = ([], [])
     work = [0]
     rounds = 0
     while work:
@@ -131,7 +154,7 @@ def check_kernel(lines, start):
     for k, b in enumerate(blocks):
         if state_in[k] is not None:
             transfer(b, state_in[k], viol)
-    n_loads = sum(1 for l in body if "global_load_dwordx4" in l)
+    n_loads = sum(1 for l in body if "global_load_dwordx4" in l or "ds_read_b128" in l)
     return [(ln,) + viol[ln] for ln in sorted(viol)], n_loads
 
 
