@@ -33,6 +33,13 @@ struct Net {
   float* d_wpack_fwd = nullptr;
   float* d_wpack_bwd = nullptr;
   float* d_vecpack = nullptr;
+  // bf16 path (cfg.dtype == NERFHIP_BF16): fragment streams (bf16_common.cuh) and fp32 vectors
+  std::vector<FragDesc> bf_full, bf_sigma;      // forward stream with the colour head / with the density tile only
+  FragDesc* d_bf_full_desc = nullptr;
+  FragDesc* d_bf_sigma_desc = nullptr;
+  void* d_bf_full = nullptr;
+  void* d_bf_sigma = nullptr;
+  float* d_bvec = nullptr;
   float* d_dirfeat = nullptr;  // [max_rays][max(32*HT, 12)]
   float* d_encdirT = nullptr;  // training, mode 1: [32][Bpad]
   float* d_ddirT = nullptr;    // training, mode 1: d(dirvec)^T [32*HT][Bpad]
@@ -170,6 +177,51 @@ void build_chunks(Net& n) {
   n.off_bwd.push_back(off);
 }
 
+// bf16 forward streams: fragments in consumption order, every layer part padded to a whole 32-fragment block
+void build_bf16_streams(Net& n) {
+  const NetLayout& L = n.L;
+  const int W = L.W, WT = n.WT;
+  const int HT = L.mode == 1 ? std::max(1, WT / 2) : 1;   // colour-hidden tiles (kernel template)
+  auto pad = [](std::vector<FragDesc>& v) {
+    while (v.size() % 32) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 0});
+  };
+  auto ksteps = [&](std::vector<FragDesc>& v, int64_t off, int ld, int row0, int nrows, int col_base, int kfeat) {
+    for (int kt = 0; kt * 32 < kfeat; ++kt)
+      for (int s = 0; s < 2; ++s)
+        v.push_back(FragDesc{off, ld, row0, nrows, col_base + 32 * kt, std::max(0, std::min(32, kfeat - 32 * kt)), s, 0});
+  };
+  auto trunk = [&](std::vector<FragDesc>& v) {
+    for (int l = 0; l < L.D; ++l) {
+      const bool uses_act = l > 0;
+      const bool uses_enc = l == 0 || ((L.skip_mask >> (l - 1)) & 1u);
+      for (int ot = 0; ot < WT; ++ot) {
+        if (uses_act) ksteps(v, L.w_off[l], L.fan_in[l], 32 * ot, W, 0, W);
+        if (uses_enc) {   // always 2 k-tiles (64 padded encoding rows)
+          const int c0 = uses_act ? W : 0;
+          for (int kt = 0; kt < 2; ++kt)
+            for (int s = 0; s < 2; ++s)
+              v.push_back(FragDesc{L.w_off[l], L.fan_in[l], 32 * ot, W, c0 + 32 * kt, std::max(0, std::min(32, L.E - 32 * kt)), s, 0});
+        }
+      }
+      pad(v);
+    }
+  };
+  n.bf_full.clear(); n.bf_sigma.clear();
+  trunk(n.bf_full);
+  for (int ot = 0; ot < HT; ++ot) ksteps(n.bf_full, L.wf_off, W, 32 * ot, L.head_rows, 0, W);
+  ksteps(n.bf_full, L.ws_off, W, 0, 1, 0, W);   // density tile: row 0
+  pad(n.bf_full);
+  if (L.mode == 1) {
+    for (int kt = 0; kt < HT; ++kt)
+      for (int s = 0; s < 2; ++s)
+        n.bf_full.push_back(FragDesc{L.wc_off, L.H2, 0, 3, 32 * kt, std::max(0, std::min(32, L.H2 - 32 * kt)), s, 0});
+    pad(n.bf_full);
+  }
+  trunk(n.bf_sigma);
+  ksteps(n.bf_sigma, L.ws_off, W, 0, 1, 0, W);
+  pad(n.bf_sigma);
+}
+
 NetArgs net_args(const nerfhip* h, const Net& n) {
   NetArgs a{};
   a.params = h->d_params + n.param_off;
@@ -235,6 +287,11 @@ int repack(nerfhip* h) {
     HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));
     HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
     HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
+    if (h->cfg.dtype == NERFHIP_BF16) {
+      HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_full_desc, (int)n.bf_full.size(), n.d_bf_full, h->stream));
+      HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_sigma_desc, (int)n.bf_sigma.size(), n.d_bf_sigma, h->stream));
+      HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, h->stream));
+    }
   }
   h->packed = true;
   return NERFHIP_OK;
@@ -253,12 +310,17 @@ int dir_features(nerfhip* h, Net& n, const float* viewdir, int64_t nr, bool trai
 
 int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const float* d, const float* z, int64_t nr, int S,
                 float* sigma, float* craw, bool want_rgb) {
-  if (h->cfg.dtype != NERFHIP_F32) return fail(h, NERFHIP_E_INVALID, "bf16 MLP path not built in this version");
   Scope sc(h, P_MLP_FWD);
-  ActStore st = n.st;
-  st.Mpad = (nr * S + kTile - 1) / kTile * kTile;
-  HIPCHK(h, launch_mlp_fwd_f32(train_store, net_args(h, n), o, d, z, n.d_dirfeat, nr * S, S, sigma, craw,
-                               want_rgb ? 1 : 0, st, h->stream));
+  if (h->cfg.dtype == NERFHIP_BF16) {
+    if (train_store) return fail(h, NERFHIP_E_INVALID, "bf16 training path not built in this version");
+    HIPCHK(h, launch_mlp_fwd_bf16(net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z, n.d_dirfeat,
+                                  nr * S, S, sigma, craw, want_rgb ? 1 : 0, h->stream));
+  } else {
+    ActStore st = n.st;
+    st.Mpad = (nr * S + kTile - 1) / kTile * kTile;
+    HIPCHK(h, launch_mlp_fwd_f32(train_store, net_args(h, n), o, d, z, n.d_dirfeat, nr * S, S, sigma, craw,
+                                 want_rgb ? 1 : 0, st, h->stream));
+  }
   h->flop_fwd += net_fwd_flop_per_sample(n, want_rgb) * (double)nr * S;
   h->fwd_launches++;
   return NERFHIP_OK;
@@ -456,6 +518,19 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
     CCHK(hipMemsetAsync(n.d_wpack_fwd, 0, ((size_t)n.off_fwd.back() + pad) * sizeof(float), h->stream));
     CCHK(hipMemsetAsync(n.d_wpack_bwd, 0, ((size_t)n.off_bwd.back() + pad) * sizeof(float), h->stream));
     CCHK(dalloc(&n.d_vecpack, (size_t)vecpack_floats(L.D, L.W)));
+    if (c.dtype == NERFHIP_BF16) {
+      build_bf16_streams(n);
+      const size_t padf = 4 * 32;   // the LDS ring requests up to 3 blocks past the end
+      CCHK(dalloc(&n.d_bf_full_desc, n.bf_full.size()));
+      CCHK(dalloc(&n.d_bf_sigma_desc, n.bf_sigma.size()));
+      CCHK(hipMemcpy(n.d_bf_full_desc, n.bf_full.data(), n.bf_full.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMemcpy(n.d_bf_sigma_desc, n.bf_sigma.data(), n.bf_sigma.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMalloc(&n.d_bf_full, (n.bf_full.size() + padf) * 1024));
+      CCHK(hipMalloc(&n.d_bf_sigma, (n.bf_sigma.size() + padf) * 1024));
+      CCHK(hipMemsetAsync(n.d_bf_full, 0, (n.bf_full.size() + padf) * 1024, h->stream));
+      CCHK(hipMemsetAsync(n.d_bf_sigma, 0, (n.bf_sigma.size() + padf) * 1024, h->stream));
+      CCHK(dalloc(&n.d_bvec, (size_t)L.D * L.W + 5 * 32 + 32));
+    }
     CCHK(dalloc(&n.d_dirfeat, (size_t)h->R * std::max(32 * n.HT, 12)));
   }
   const size_t R = (size_t)h->R, N = h->N, S = h->S, NI = std::max(h->NI, 1);
@@ -483,7 +558,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
-    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd);
+    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec);
     fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
     fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.st.mask); fr(n.d_dsigma); fr(n.d_dcraw);
   }

@@ -1,0 +1,180 @@
+// bf16_common.cuh -- machinery of the bf16-MFMA MLP kernels (gfx950, v_mfma_f32_32x32x16_bf16).
+//
+// Same transposed formulation as the fp32 kernels (mlp_common.cuh): activations H^T [features][samples] with
+// the sample on the lane, weights as the A operand, fp32 accumulators.  What changes with bf16:
+//   * one MFMA contracts 16 features (lane half h holds 8 consecutive-in-register bf16) and takes 8 passes, i.e.
+//     16x the fp32 rate: the A fragments (1 KiB per wave per MFMA) can no longer come from L2 -- they are staged
+//     through LDS and each fragment is used for NS = 2 sample tiles (a wave owns 64 samples);
+//   * the loop is OUTPUT-TILE outer: all K of one 32-row output tile is accumulated before the next tile
+//     starts, so only 2 x NS accumulator tiles are live, the ReLU + bf16 conversion of tile t runs in the shadow
+//     of tile t+1's MFMAs, and the converted tile is directly a B operand of the next layer:
+//     accumulator register r = 8s + e of a tile holds feature  F(s,h,e) = 16s + (e&3) + 8(e>>2) + 4h,
+//     so registers 8s..8s+7 of both lane halves are exactly the 16 features of k-step s; the weight fragment of
+//     (k-tile kt, step s, output tile ot) is packed in that same order (pack.hip: pack_frags_bf16_kernel).
+//
+// Weight stream: one flat sequence of 1-KiB fragments in consumption order, every layer part padded to a
+// multiple of 32 fragments.  It moves through a ring of kRing LDS slots in fixed 32-KiB blocks by LDS-DMA
+// (global_load_lds 16 B; every wave moves 8 KiB of each block): during block k every wave passes ONE sync point
+// P_k (own pieces of block k+1 landed [counted vmcnt] -> s_barrier -> request block k+3), placed 4 fragments
+// before the end of the block so the fragment prefetch (3 ahead, asm ds_read_b128 with counted lgkmcnt) runs
+// across block boundaries without a bubble.  The allocation is padded so requests past the end stay in bounds.
+#pragma once
+#include "mlp_common.cuh"
+
+namespace nh {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kNS = 2;                 // sample tiles (of 32) per wave
+constexpr int kBfTile = 4 * kNS * 32;  // samples per workgroup
+constexpr int kBlkFrags = 32;
+constexpr int kBlkBytes = kBlkFrags * 1024;
+constexpr int kRing = 4;
+constexpr int kSyncFrag = 28;          // position of the sync point inside a block
+constexpr int kPD = 3;                 // fragments fetched ahead
+
+// feature (inside a 32-feature tile) held by element e of k-step s in lane half h
+__device__ __host__ constexpr int bf_feature(int s, int h, int e) { return 16 * s + (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+struct BfRing {
+  const char* stream;   // packed fragments (global)
+  float* ring;          // LDS ring, slot 0
+  uint32_t ring_addr;   // LDS byte address of slot 0 + lane*16
+  int blk;              // block being consumed
+  int wave, lane;
+  __device__ __forceinline__ void request(int b) const {
+    const char* src = stream + (size_t)b * kBlkBytes + wave * (kBlkBytes / 4) + lane * 16;
+    char* dst = reinterpret_cast<char*>(ring) + (b & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / 4);
+#pragma unroll
+    for (int p = 0; p < kBlkBytes / 4 / 1024; ++p)
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + p * 1024), NERFHIP_LPTR(dst + p * 1024), 16, 0, 0);
+  }
+  // kernel prologue: blocks 0..2 requested, block 0 visible
+  __device__ __forceinline__ void start() {
+    blk = 0;
+    request(0); request(1); request(2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // sync point P_blk: block blk+1 visible to every wave, slot of block blk-1 handed to block blk+3
+  __device__ __forceinline__ void sync_point() const {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    request(blk + 3);
+  }
+  __device__ __forceinline__ uint32_t slot_addr(int b) const { return ring_addr + (uint32_t)(b & (kRing - 1)) * kBlkBytes; }
+};
+
+template <int IMM>
+__device__ __forceinline__ void lds_read_frag(bf16x8& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+template <int IMM>
+__device__ __forceinline__ void lds_read_f4(f32x4& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm_n() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N)); }
+
+// accumulator-init rows of one output tile (bias, or any per-feature fp32 vector laid out like a bias):
+// 4 x 16 B per lane, features 32 ot + 8q + 4h + {0..3}
+struct BiasBuf { f32x4 q[4]; };
+template <int OT_>
+__device__ __forceinline__ void bias_read(BiasBuf& b, uint32_t addr) {   // addr: vector base + h*16
+  lds_read_f4<(32 * OT_ + 0) * 4>(b.q[0], addr);
+  lds_read_f4<(32 * OT_ + 8) * 4>(b.q[1], addr);
+  lds_read_f4<(32 * OT_ + 16) * 4>(b.q[2], addr);
+  lds_read_f4<(32 * OT_ + 24) * 4>(b.q[3], addr);
+}
+__device__ __forceinline__ f32x16 bias_value(BiasBuf& b) {   // call only behind the wait that retired the reads
+  asm volatile("" : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]));
+  f32x16 c;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { c[4 * q] = b.q[q][0]; c[4 * q + 1] = b.q[q][1]; c[4 * q + 2] = b.q[q][2]; c[4 * q + 3] = b.q[q][3]; }
+  return c;
+}
+
+// ---- one layer part: OT output tiles x KS k-steps, fragments j = ot*KS + ks ---------------------------------
+// BSel:  template <int KS_IDX> const bf16x8& b(int n) const      B operand of k-step KS_IDX for sample tile n
+// Epi:   template <int OT_IDX> void done(f32x16 (&acc)[kNS])     called when output tile OT_IDX is complete
+template <int KS, int OT>
+struct PartSched {
+  static constexpr int NF = KS * OT;
+  static constexpr int frag_ops(int t) { return t + kPD < NF ? 1 : 0; }
+  static constexpr int bias_ops(int t) { return (t % KS == 0 && t / KS + 1 < OT) ? 4 : 0; }
+  // LDS operations issued behind fragment j's read up to the wait of step j (see file header)
+  static constexpr int pending(int j) {
+    int n = 0;
+    if (j < kPD) {
+      n = kPD - 1 - j;
+      for (int t = 0; t <= j; ++t) n += frag_ops(t) + bias_ops(t);
+    } else {
+      n = bias_ops(j - kPD);
+      for (int t = j - kPD + 1; t <= j; ++t) n += frag_ops(t) + bias_ops(t);
+    }
+    return n;
+  }
+  // is the sync point of the block that fragment j lies in executed right after step j?
+  static constexpr bool sync_after(int j) { return (j % kBlkFrags == kSyncFrag) || (j == NF - 1 && (j % kBlkFrags) < kSyncFrag); }
+};
+
+template <int KS, int OT, class BSel, class Epi, int J>
+struct PartStep {
+  using S = PartSched<KS, OT>;
+  static __device__ __forceinline__ void run(BfRing& rg, int blk0, uint32_t bias_addr, bf16x8 (&fr)[kPD + 1], BiasBuf (&bias)[2],
+                                             f32x16 (&acc)[2][kNS], const BSel& bsel, Epi& epi) {
+    constexpr int ot = J / KS, ks = J % KS;
+    if constexpr (J + kPD < S::NF) {
+      constexpr int jj = J + kPD;
+      lds_read_frag<(jj % kBlkFrags) * 1024>(fr[jj % (kPD + 1)], rg.slot_addr(blk0 + jj / kBlkFrags));
+    }
+    if constexpr (ks == 0 && ot + 1 < OT) bias_read<ot + 1>(bias[(ot + 1) & 1], bias_addr);
+    wait_lgkm_n<S::pending(J)>();
+    asm volatile("" : "+v"(fr[J % (kPD + 1)]));
+    if constexpr (ks == 0) {
+      const f32x16 c0 = bias_value(bias[ot & 1]);
+#pragma unroll
+      for (int n = 0; n < kNS; ++n)
+        acc[ot & 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[J % (kPD + 1)], bsel.template b<ks>(n), c0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int n = 0; n < kNS; ++n)
+        acc[ot & 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[J % (kPD + 1)], bsel.template b<ks>(n), acc[ot & 1][n], 0, 0, 0);
+    }
+    if constexpr (ks == KS - 1) epi.template done<ot>(acc[ot & 1]);
+    if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkFrags; rg.sync_point(); }
+    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
+  }
+};
+
+// Runs one part that starts at block rg.blk (block-aligned) and leaves rg.blk at the next part's first block.
+// bias_addr: LDS byte address of the part's accumulator-init vector + h*16.
+template <int KS, int OT, class BSel, class Epi>
+__device__ __forceinline__ void run_part(BfRing& rg, uint32_t bias_addr, const BSel& bsel, Epi& epi) {
+  static_assert(KS >= 4 || OT == 1, "bias prefetch needs >= 4 k-steps per output tile");
+  using S = PartSched<KS, OT>;
+  const int blk0 = rg.blk;
+  bf16x8 fr[kPD + 1];
+  BiasBuf bias[2];
+  f32x16 acc[2][kNS];
+  __builtin_amdgcn_sched_barrier(0);
+  bias_read<0>(bias[0], bias_addr);
+  lds_read_frag<0>(fr[0], rg.slot_addr(blk0));
+  if constexpr (S::NF > 1) lds_read_frag<1024>(fr[1], rg.slot_addr(blk0));
+  if constexpr (S::NF > 2) lds_read_frag<2048>(fr[2], rg.slot_addr(blk0));
+  PartStep<KS, OT, BSel, Epi, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
+  wait_lgkm_n<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  rg.blk = blk0 + (S::NF + kBlkFrags - 1) / kBlkFrags;
+}
+
+// relu + round to bf16: accumulator tile -> the two k-step B operands of the next layer
+__device__ __forceinline__ void relu_pack(const f32x16& a, bf16x8& s0, bf16x8& s1) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s0[e] = (__bf16)fmaxf(a[e], 0.f);
+    s1[e] = (__bf16)fmaxf(a[8 + e], 0.f);
+  }
+}
+
+}  // namespace nh

@@ -40,6 +40,18 @@ struct ChunkDesc {
   uint32_t pad;
 };
 
+// One 1-KiB fragment of a packed bf16 weight stream (bf16_common.cuh): 32 rows x 16 k-values of one matrix.
+struct FragDesc {
+  int64_t src_off;     // float offset of the matrix in the canonical network parameters; < 0: all-zero fragment
+  int32_t ld;          // row length of the canonical matrix
+  int32_t row0;        // canonical row of lane i = 0 (lane i -> row0 + i)
+  int32_t nrows;       // rows of the canonical matrix (rows >= nrows read as zero)
+  int32_t col0;        // canonical column of feature 0 of the 32-feature k-tile
+  int32_t kvalid;      // features of the k-tile that exist (the rest read as zero)
+  int32_t s;           // k-step inside the k-tile (0 | 1)
+  int32_t transposed;  // 1: element (row, col) = src[col*ld + row]
+};
+
 // Kernel-side description of one network (passed by value).
 struct NetArgs {
   const float* params;         // canonical fp32 parameters of this network

@@ -41,6 +41,13 @@ hipError_t launch_mlp_fwd_f32(bool train, const NetArgs& net, const float* rays_
 hipError_t launch_mlp_bwd_f32(const NetArgs& net, const float* d_sigma, const float* d_craw, const float* dirfeat,
                               int64_t M, int S, int has_rgb, const ActStore& st, hipStream_t stream);
 
+// bf16 path
+hipError_t launch_pack_frags_bf16(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s);
+hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s);
+hipError_t launch_mlp_fwd_bf16(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+                               const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
+                               float* craw, int want_rgb, hipStream_t stream);
+
 // wgrad.hip
 struct WgradItem {
   const float* A;

@@ -1,0 +1,250 @@
+// mlp_fwd_bf16.hip -- fused positional-encoding + density/colour MLP forward on bf16 MFMA (gfx950), inference.
+//
+// Same function as mlp_fwd.hip (reference nerf/nerfCoreBlock.scala:17-112) with bf16 MFMA operands and fp32
+// accumulation (BASELINE config 5; parity bar: renders within 1e-2 abs of the fp32 path).  Positions, the
+// encoding's sin/cos, biases, the per-ray view-direction branch and all accumulators are fp32; weights and
+// the activations fed to the next layer are rounded to bf16 (RNE).  Machinery: bf16_common.cuh.
+// One wave = 64 samples (2 MFMA sample tiles) x all features; workgroup = 256 samples.
+// Stream layout (api.hip: build_bf16_stream): layer 0 | layers 1..D-1 (skip layers carry 4 extra k-steps for
+// the encoding) | head: HT colour-hidden tiles + one tile whose row 0 is the density row | (mode 1) colour
+// output layer, 1 tile over K = 32 HT.  The sigma-only stream (coarse pass of inference) ends with the density
+// tile alone.
+#include "bf16_common.cuh"
+#include "launchers.h"
+
+namespace nh {
+
+template <int WT>
+struct ActRegs { bf16x8 v[kNS][WT][2]; };
+
+template <int WT>
+struct SelAct {   // k-steps 0 .. 2WT-1: previous layer; 2WT .. 2WT+3: encoding (skip layers)
+  const ActRegs<WT>& a;
+  const ActRegs<2>& e;
+  template <int KS_IDX> __device__ __forceinline__ const bf16x8& b(int n) const {
+    if constexpr (KS_IDX < 2 * WT) return a.v[n][KS_IDX / 2][KS_IDX % 2];
+    else return e.v[n][(KS_IDX - 2 * WT) / 2][KS_IDX % 2];
+  }
+};
+struct SelEnc {
+  const ActRegs<2>& e;
+  template <int KS_IDX> __device__ __forceinline__ const bf16x8& b(int n) const { return e.v[n][KS_IDX / 2][KS_IDX % 2]; }
+};
+template <int HT>
+struct SelHid {
+  const ActRegs<HT>& a;
+  template <int KS_IDX> __device__ __forceinline__ const bf16x8& b(int n) const { return a.v[n][KS_IDX / 2][KS_IDX % 2]; }
+};
+template <int WT>
+struct EpiTrunk {   // relu + bf16 -> B operand of the next layer
+  ActRegs<WT>& out;
+  template <int OT_IDX> __device__ __forceinline__ void done(f32x16 (&acc)[kNS]) {
+#pragma unroll
+    for (int n = 0; n < kNS; ++n) relu_pack(acc[n], out.v[n][OT_IDX][0], out.v[n][OT_IDX][1]);
+  }
+};
+
+struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
+  float* sigma; const int64_t* m; const bool* valid; int h;
+  template <int OT_IDX> __device__ __forceinline__ void done(f32x16 (&acc)[kNS]) {
+#pragma unroll
+    for (int n = 0; n < kNS; ++n)
+      if (valid[n] && h == 0) sigma[m[n]] = acc[n][0];
+  }
+};
+template <int HT, int MODE>
+struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
+  ActRegs<HT>& hid; float (&c)[kNS][3];
+  const float* dirfeat; const int64_t* ray; const int64_t* m; const bool* valid; float* sigma; int h;
+  template <int OT_IDX> __device__ __forceinline__ void done(f32x16 (&acc)[kNS]) {
+    if constexpr (OT_IDX == HT) {
+#pragma unroll
+      for (int n = 0; n < kNS; ++n)
+        if (valid[n] && h == 0) sigma[m[n]] = acc[n][0];
+    } else if constexpr (MODE == 1) {
+      // add().relu() (nerfCoreBlock.scala:67): + (Wd.enc(dir) + bd + bf) of the sample's ray, fp32
+#pragma unroll
+      for (int n = 0; n < kNS; ++n) {
+        const float* df = dirfeat + ray[n] * (32 * HT) + 32 * OT_IDX + 4 * h;
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(df + 8 * q);
+          v[4 * q] = acc[n][4 * q] + d[0]; v[4 * q + 1] = acc[n][4 * q + 1] + d[1];
+          v[4 * q + 2] = acc[n][4 * q + 2] + d[2]; v[4 * q + 3] = acc[n][4 * q + 3] + d[3];
+        }
+        relu_pack(v, hid.v[n][OT_IDX][0], hid.v[n][OT_IDX][1]);
+      }
+    } else if constexpr (MODE == 2) {
+      // reshape(...,9,3).mul(SH).sum(-2) (:55): c[k] = sum_j q[3j+k] * Y_j(dir); rows 0..26 of tile 0
+#pragma unroll
+      for (int n = 0; n < kNS; ++n) {
+        const float* Y = dirfeat + ray[n] * 12;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = tile_row(0, r, h);
+          if (row < 27) {
+            const int j = row / 3, k = row - 3 * j;
+            const float v = acc[n][r] * Y[j];
+            c[n][0] += k == 0 ? v : 0.f; c[n][1] += k == 1 ? v : 0.f; c[n][2] += k == 2 ? v : 0.f;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < kNS; ++n)
+        if (h == 0) { c[n][0] = acc[n][0]; c[n][1] = acc[n][1]; c[n][2] = acc[n][2]; }
+    }
+  }
+};
+struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
+  float (&c)[kNS][3]; int h;
+  template <int OT_IDX> __device__ __forceinline__ void done(f32x16 (&acc)[kNS]) {
+#pragma unroll
+    for (int n = 0; n < kNS; ++n)
+      if (h == 0) { c[n][0] = acc[n][0]; c[n][1] = acc[n][1]; c[n][2] = acc[n][2]; }
+  }
+};
+
+template <int WT, int MODE>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const char* __restrict__ stream,
+                                                              const float* __restrict__ bvec,
+                                                              const float* __restrict__ rays_o,
+                                                              const float* __restrict__ rays_d,
+                                                              const float* __restrict__ z,
+                                                              const float* __restrict__ dirfeat, int64_t M, int S,
+                                                              float* __restrict__ sigma, float* __restrict__ craw,
+                                                              int want_rgb) {
+  constexpr int R = 32 * WT;
+  constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
+  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring (kRing x 32 KiB) | vectors
+  float* vec = smem + kRing * kBlkBytes / 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = net.D;
+  const int nvec = D * R + (HT + 1) * 32 + 32;
+
+  BfRing rg;
+  rg.stream = stream;
+  rg.ring = smem;
+  rg.ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem + (uint32_t)lane * 16u;
+  rg.wave = wave;
+  rg.lane = lane;
+  for (int i = tid; i < nvec; i += 256) vec[i] = bvec[i];
+  const uint32_t vec_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)vec + (uint32_t)h * 16u;
+
+  int64_t m[kNS], ray[kNS];
+  bool valid[kNS];
+  ActRegs<2> enc;
+#pragma unroll
+  for (int n = 0; n < kNS; ++n) {
+    m[n] = (int64_t)blockIdx.x * kBfTile + wave * (32 * kNS) + n * 32 + li;
+    valid[n] = m[n] < M;
+    const int64_t mc = valid[n] ? m[n] : M - 1;
+    ray[n] = mc / S;
+    // sample position (raysO.add(raysD.mul(zVals)), nerfBlock.scala:65): separate mul and add, fp32
+    const float zz = z[mc];
+    const float px = __fadd_rn(rays_o[ray[n] * 3 + 0], __fmul_rn(rays_d[ray[n] * 3 + 0], zz));
+    const float py = __fadd_rn(rays_o[ray[n] * 3 + 1], __fmul_rn(rays_d[ray[n] * 3 + 1], zz));
+    const float pz = __fadd_rn(rays_o[ray[n] * 3 + 2], __fmul_rn(rays_d[ray[n] * 3 + 2], zz));
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) enc.v[n][kt][s][e] = (__bf16)code_value(px, py, pz, 32 * kt + bf_feature(s, h, e), net.E);
+  }
+  __syncthreads();   // vectors visible
+  rg.start();
+
+  ActRegs<WT> act, nxt;
+  {
+    EpiTrunk<WT> epi{act};
+    run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
+  }
+  for (int l = 1; l < D; ++l) {
+    EpiTrunk<WT> epi{nxt};
+    const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
+    if ((net.skip_mask >> (l - 1)) & 1u) run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{act, enc}, epi);
+    else run_part<2 * WT, WT>(rg, baddr, SelAct<WT>{act, enc}, epi);
+    act = nxt;
+  }
+
+  const uint32_t haddr = vec_addr + (uint32_t)(D * R) * 4u;
+  if (!want_rgb) {
+    // sigma-only stream: one tile, row 0 = density row (nerfCoreBlock.scala:39-40)
+    EpiSigma epi{sigma, m, valid, h};
+    run_part<2 * WT, 1>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, enc}, epi);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+    return;
+  }
+
+  // head: HT colour tiles, then the density tile
+  ActRegs<HT> hid;
+  float c[kNS][3];
+#pragma unroll
+  for (int n = 0; n < kNS; ++n) c[n][0] = c[n][1] = c[n][2] = 0.f;
+  EpiHead<HT, MODE> epih{hid, c, dirfeat, ray, m, valid, sigma, h};
+  run_part<2 * WT, HT + 1>(rg, haddr, SelAct<WT>{act, enc}, epih);
+
+  if constexpr (MODE == 1) {
+    // colour output layer: Linear(3) over the H2 hidden features, as one MFMA tile (rows 0..2)
+    EpiColour epic{c, h};
+    run_part<2 * HT, 1>(rg, haddr + (uint32_t)((HT + 1) * 32) * 4u, SelHid<HT>{hid}, epic);
+  } else if constexpr (MODE == 2) {
+#pragma unroll
+    for (int n = 0; n < kNS; ++n) {
+      c[n][0] += __shfl_xor(c[n][0], 32); c[n][1] += __shfl_xor(c[n][1], 32); c[n][2] += __shfl_xor(c[n][2], 32);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+#pragma unroll
+  for (int n = 0; n < kNS; ++n)
+    if (valid[n] && h == 0) { craw[m[n] * 3 + 0] = c[n][0]; craw[m[n] * 3 + 1] = c[n][1]; craw[m[n] * 3 + 2] = c[n][2]; }
+}
+
+template <int WT, int MODE>
+static hipError_t launch_one(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+                             const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
+                             float* craw, int want_rgb, hipStream_t stream) {
+  constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
+  const size_t lds = (size_t)kRing * kBlkBytes + ((size_t)net.D * 32 * WT + (HT + 1) * 32 + 32) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)((M + kBfTile - 1) / kBfTile)), block(256);
+  hipLaunchKernelGGL((mlp_fwd_bf16_kernel<WT, MODE>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
+                     rays_d, z, dirfeat, M, S, sigma, craw, want_rgb);
+  return hipGetLastError();
+}
+
+template <int WT>
+static hipError_t launch_mode(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+                              const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
+                              float* craw, int want_rgb, hipStream_t stream) {
+  switch (net.mode) {
+    case 1: return launch_one<WT, 1>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
+    case 2: return launch_one<WT, 2>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
+    default: return launch_one<WT, 0>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
+  }
+}
+
+// stream_w: the full stream when want_rgb, else the sigma-only stream (api.hip)
+hipError_t launch_mlp_fwd_bf16(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+                               const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
+                               float* craw, int want_rgb, hipStream_t stream) {
+  switch (net.W / 32) {
+    case 2: return launch_mode<2>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
+    case 4: return launch_mode<4>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
+    case 8: return launch_mode<8>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace nh

@@ -27,6 +27,47 @@ __global__ void pack_chunks_kernel(const float* __restrict__ params, const Chunk
   }
 }
 
+// bf16 weight streams: one block (64 lanes) per fragment; lane (h, i) writes 8 bf16 = W[row0+i][col0 + F(s,h,e)]
+__global__ __launch_bounds__(64) void pack_frags_bf16_kernel(const float* __restrict__ params,
+                                                             const FragDesc* __restrict__ descs,
+                                                             __bf16* __restrict__ dst) {
+  const FragDesc d = descs[blockIdx.x];
+  const int lane = threadIdx.x, h = lane >> 5, i = lane & 31;
+  const float* src = params + (d.src_off < 0 ? 0 : d.src_off);
+  __bf16* o = dst + ((int64_t)blockIdx.x * 64 + lane) * 8;
+  const int row = d.row0 + i;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int f = 16 * d.s + (e & 3) + 8 * (e >> 2) + 4 * h;   // bf16_common.cuh: bf_feature
+    float v = 0.f;
+    if (d.src_off >= 0 && row < d.nrows && f < d.kvalid)
+      v = d.transposed ? src[(int64_t)(d.col0 + f) * d.ld + row] : src[(int64_t)row * d.ld + d.col0 + f];
+    o[e] = (__bf16)v;
+  }
+}
+
+// bf16 path vectors (fp32): [D*W] trunk biases | [(HT+1)*32] head accumulator init (mode 1: zero, the per-ray
+// direction vector carries bf + bd; else bf; tile HT: b_sigma at row 0) | [32] colour bias (mode 1)
+__global__ void pack_bvec_kernel(const float* __restrict__ params, NetLayout L, int HT, float* __restrict__ bv) {
+  const int W = L.W, D = L.D;
+  const int total = D * W + (HT + 1) * 32 + 32;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (idx < D * W) {
+      v = params[L.b_off[idx / W] + idx % W];
+    } else if (idx < D * W + HT * 32) {
+      const int j = idx - D * W;
+      if (L.mode != 1 && j < L.head_rows) v = params[L.bf_off + j];
+    } else if (idx < D * W + (HT + 1) * 32) {
+      if (idx == D * W + HT * 32) v = params[L.bs_off];
+    } else {
+      const int j = idx - (D * W + (HT + 1) * 32);
+      if (L.mode == 1 && j < 3) v = params[L.bc_off + j];
+    }
+    bv[idx] = v;
+  }
+}
+
 __global__ void pack_vec_kernel(const float* __restrict__ params, NetLayout L, int HT, float* __restrict__ vp) {
   const int W = L.W, D = L.D, Rh = 32 * HT;
   const int total = (D + 5) * W + 4;
@@ -170,6 +211,15 @@ __global__ void init_kernel(float* __restrict__ p, InitSeg seg, uint64_t seed) {
 hipError_t launch_pack_chunks(const float* params, const ChunkDesc* descs, int n, float* dst, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(pack_chunks_kernel, dim3(n), dim3(256), 0, s, params, descs, dst);
+  return hipGetLastError();
+}
+hipError_t launch_pack_frags_bf16(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_frags_bf16_kernel, dim3(n), dim3(64), 0, s, params, descs, (__bf16*)dst);
+  return hipGetLastError();
+}
+hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s) {
+  hipLaunchKernelGGL(pack_bvec_kernel, dim3(16), dim3(256), 0, s, params, L, HT, bv);
   return hipGetLastError();
 }
 hipError_t launch_pack_vec(const float* params, const NetLayout& L, int HT, float* vp, hipStream_t s) {
