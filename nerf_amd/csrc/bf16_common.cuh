@@ -96,7 +96,10 @@ __device__ __forceinline__ f32x16 bias_value(BiasBuf& b) {   // call only behind
 
 // ---- one layer part: OT output tiles x KS k-steps, fragments j = ot*KS + ks ---------------------------------
 // BSel:  template <int KS_IDX> const bf16x8& b(int n) const      B operand of k-step KS_IDX for sample tile n
-// Epi:   template <int OT_IDX> void done(f32x16 (&acc)[kNS])     called when output tile OT_IDX is complete
+// Epi:   static constexpr int kPieces;  template <int OT_IDX, int P> void piece(f32x16 (&acc)[kNS])
+//        the epilogue of a finished output tile, cut into kPieces pieces which are spread over the k-steps of the
+//        NEXT tile (accumulators are double buffered), so its VALU work issues between that tile's MFMAs instead
+//        of stalling on the last MFMA's result with the matrix pipe idle; the last tile's pieces run at the end.
 template <int KS, int OT>
 struct PartSched {
   static constexpr int NF = KS * OT;
@@ -106,7 +109,7 @@ struct PartSched {
   static constexpr int pending(int j) {
     int n = 0;
     if (j < kPD) {
-      n = kPD - 1 - j;
+      n = (NF < kPD ? NF : kPD) - 1 - j;   // the prime reads min(kPD, NF) fragments
       for (int t = 0; t <= j; ++t) n += frag_ops(t) + bias_ops(t);
     } else {
       n = bias_ops(j - kPD);
@@ -116,6 +119,18 @@ struct PartSched {
   }
   // is the sync point of the block that fragment j lies in executed right after step j?
   static constexpr bool sync_after(int j) { return (j % kBlkFrags == kSyncFrag) || (j == NF - 1 && (j % kBlkFrags) < kSyncFrag); }
+};
+
+template <int KS, int NP>
+constexpr int piece_offset(int p) { return (p * KS) / NP + (KS >= 8 ? 1 : 0); }
+template <int KS, class Epi, int OT_IDX, int OFF, int P = 0>
+struct EpiPieces {   // runs the pieces of tile OT_IDX scheduled at k-step offset OFF (OFF < 0: all)
+  static __device__ __forceinline__ void run(Epi& epi, f32x16 (&acc)[kNS]) {
+    if constexpr (P < Epi::kPieces) {
+      if constexpr (OFF < 0 || piece_offset<KS, Epi::kPieces>(P) == OFF) epi.template piece<OT_IDX, P>(acc);
+      EpiPieces<KS, Epi, OT_IDX, OFF, P + 1>::run(epi, acc);
+    }
+  }
 };
 
 template <int KS, int OT, class BSel, class Epi, int J>
@@ -141,7 +156,8 @@ struct PartStep {
       for (int n = 0; n < kNS; ++n)
         acc[ot & 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[J % (kPD + 1)], bsel.template b<ks>(n), acc[ot & 1][n], 0, 0, 0);
     }
-    if constexpr (ks == KS - 1) epi.template done<ot>(acc[ot & 1]);
+    if constexpr (ot >= 1) EpiPieces<KS, Epi, ot - 1, ks>::run(epi, acc[(ot - 1) & 1]);
+    if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<KS, Epi, ot, -1>::run(epi, acc[ot & 1]);
     if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkFrags; rg.sync_point(); }
     if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   }
@@ -152,6 +168,7 @@ struct PartStep {
 template <int KS, int OT, class BSel, class Epi>
 __device__ __forceinline__ void run_part(BfRing& rg, uint32_t bias_addr, const BSel& bsel, Epi& epi) {
   static_assert(KS >= 4 || OT == 1, "bias prefetch needs >= 4 k-steps per output tile");
+  static_assert(OT == 1 || piece_offset<KS, Epi::kPieces>(Epi::kPieces - 1) < KS, "epilogue pieces must fit into the next tile");
   using S = PartSched<KS, OT>;
   const int blk0 = rg.blk;
   bf16x8 fr[kPD + 1];
@@ -168,13 +185,44 @@ __device__ __forceinline__ void run_part(BfRing& rg, uint32_t bias_addr, const B
   rg.blk = blk0 + (S::NF + kBlkFrags - 1) / kBlkFrags;
 }
 
-// relu + round to bf16: accumulator tile -> the two k-step B operands of the next layer
-__device__ __forceinline__ void relu_pack(const f32x16& a, bf16x8& s0, bf16x8& s1) {
+// round to bf16 (RNE), then ReLU on the packed pairs: a negative bf16 has its sign bit set, i.e. is a negative
+// int16, so one v_pk_max_i16 against 0 clears both halves (-0 -> +0 as well) -- 1 VALU per 2 values instead of 2-4.
+// accumulator tile -> the two k-step B operands of the next layer
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 relu_bf16x8(bf16x8 x) {
+  i16x8 v = __builtin_bit_cast(i16x8, x);
+  const i16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  v = __builtin_elementwise_max(v, zero);
+  return __builtin_bit_cast(bf16x8, v);
+}
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+// registers 8 s .. 8 s + 7 of an accumulator tile -> B operand of k-step s of the next layer
+template <int S_>
+__device__ __forceinline__ bf16x8 relu_pack_half(const f32x16& a) {
+  f32x8 v;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    s0[e] = (__bf16)fmaxf(a[e], 0.f);
-    s1[e] = (__bf16)fmaxf(a[8 + e], 0.f);
-  }
+  for (int e = 0; e < 8; ++e) v[e] = a[8 * S_ + e];
+  return relu_bf16x8(__builtin_convertvector(v, bf16x8));   // v_cvt_pk_bf16_f32 (RNE), two values per instruction
+}
+__device__ __forceinline__ void relu_pack(const f32x16& a, bf16x8& s0, bf16x8& s1) {
+  s0 = relu_pack_half<0>(a);
+  s1 = relu_pack_half<1>(a);
+}
+
+// positionCode value for the bf16 path: hardware sin/cos (v_sin_f32 takes revolutions, |arg| <= 256, so the
+// argument is reduced with fract first).  Absolute error <= ~3e-4 at the largest frequency (|x 2^9| ~ 3000 rad:
+// fp32 rounding of x/2pi), an order of magnitude below the bf16 rounding (4e-3 relative) applied right after.
+__device__ __forceinline__ float code_value_fast(float px, float py, float pz, int e, int E) {
+  if (e >= E) return 0.f;
+  if (e < 3) return e == 0 ? px : (e == 1 ? py : pz);
+  const int t = e - 3;
+  const int f = t / 6;
+  const int rem = t - 6 * f;
+  const int c = rem >= 3 ? rem - 3 : rem;
+  const float x = c == 0 ? px : (c == 1 ? py : pz);
+  const float rev = __builtin_amdgcn_fractf(x * (float)(1 << f) * 0.15915494309189535f);
+  return rem >= 3 ? __builtin_amdgcn_cosf(rev) : __builtin_amdgcn_sinf(rev);
 }
 
 }  // namespace nh

@@ -38,15 +38,16 @@ struct SelHid {
 template <int WT>
 struct EpiTrunk {   // relu + bf16 -> B operand of the next layer
   ActRegs<WT>& out;
-  template <int OT_IDX> __device__ __forceinline__ void done(f32x16 (&acc)[kNS]) {
-#pragma unroll
-    for (int n = 0; n < kNS; ++n) relu_pack(acc[n], out.v[n][OT_IDX][0], out.v[n][OT_IDX][1]);
+  static constexpr int kPieces = 2 * kNS;   // (sample tile, k-step half)
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
+    out.v[P / 2][OT_IDX][P % 2] = relu_pack_half<P % 2>(acc[P / 2]);
   }
 };
 
 struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
   float* sigma; const int64_t* m; const bool* valid; int h;
-  template <int OT_IDX> __device__ __forceinline__ void done(f32x16 (&acc)[kNS]) {
+  static constexpr int kPieces = 1;
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
 #pragma unroll
     for (int n = 0; n < kNS; ++n)
       if (valid[n] && h == 0) sigma[m[n]] = acc[n][0];
@@ -56,7 +57,8 @@ template <int HT, int MODE>
 struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
   ActRegs<HT>& hid; float (&c)[kNS][3];
   const float* dirfeat; const int64_t* ray; const int64_t* m; const bool* valid; float* sigma; int h;
-  template <int OT_IDX> __device__ __forceinline__ void done(f32x16 (&acc)[kNS]) {
+  static constexpr int kPieces = 1;
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
     if constexpr (OT_IDX == HT) {
 #pragma unroll
       for (int n = 0; n < kNS; ++n)
@@ -99,7 +101,8 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
 };
 struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
   float (&c)[kNS][3]; int h;
-  template <int OT_IDX> __device__ __forceinline__ void done(f32x16 (&acc)[kNS]) {
+  static constexpr int kPieces = 1;
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
 #pragma unroll
     for (int n = 0; n < kNS; ++n)
       if (h == 0) { c[n][0] = acc[n][0]; c[n][1] = acc[n][1]; c[n][2] = acc[n][2]; }
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
     m[n] = (int64_t)blockIdx.x * kBfTile + wave * (32 * kNS) + n * 32 + li;
     valid[n] = m[n] < M;
     const int64_t mc = valid[n] ? m[n] : M - 1;
-    ray[n] = mc / S;
+    ray[n] = (int64_t)((uint32_t)mc / (uint32_t)S);   // host guarantees M < 2^31
     // sample position (raysO.add(raysD.mul(zVals)), nerfBlock.scala:65): separate mul and add, fp32
     const float zz = z[mc];
     const float px = __fadd_rn(rays_o[ray[n] * 3 + 0], __fmul_rn(rays_d[ray[n] * 3 + 0], zz));
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) enc.v[n][kt][s][e] = (__bf16)code_value(px, py, pz, 32 * kt + bf_feature(s, h, e), net.E);
+        for (int e = 0; e < 8; ++e) enc.v[n][kt][s][e] = (__bf16)code_value_fast(px, py, pz, 32 * kt + bf_feature(s, h, e), net.E);
   }
   __syncthreads();   // vectors visible
   rg.start();
@@ -163,11 +166,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
     EpiTrunk<WT> epi{act};
     run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
   }
-  for (int l = 1; l < D; ++l) {
-    EpiTrunk<WT> epi{nxt};
+  // layers 1..D-1, two per trip (act -> nxt -> act) so the activations never have to be copied
+  auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) {
+    EpiTrunk<WT> epi{out};
     const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
-    if ((net.skip_mask >> (l - 1)) & 1u) run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{act, enc}, epi);
-    else run_part<2 * WT, WT>(rg, baddr, SelAct<WT>{act, enc}, epi);
+    if ((net.skip_mask >> (l - 1)) & 1u) run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{in, enc}, epi);
+    else run_part<2 * WT, WT>(rg, baddr, SelAct<WT>{in, enc}, epi);
+  };
+  int l = 1;
+  for (; l + 1 < D; l += 2) {
+    layer(l, act, nxt);
+    layer(l + 1, nxt, act);
+  }
+  if (l < D) {
+    layer(l, act, nxt);
     act = nxt;
   }
 
