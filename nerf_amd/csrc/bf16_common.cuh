@@ -196,14 +196,22 @@ __device__ __forceinline__ bf16x8 relu_bf16x8(bf16x8 x) {
   v = __builtin_elementwise_max(v, zero);
   return __builtin_bit_cast(bf16x8, v);
 }
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-// registers 8 s .. 8 s + 7 of an accumulator tile -> B operand of k-step s of the next layer
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// registers 8 s .. 8 s + 7 of an accumulator tile -> B operand of k-step s of the next layer:
+// per pair one v_cvt_pk_bf16_f32 (RNE) and one v_pk_max_i16
 template <int S_>
 __device__ __forceinline__ bf16x8 relu_pack_half(const f32x16& a) {
-  f32x8 v;
+  u32x4 r;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = a[8 * S_ + e];
-  return relu_bf16x8(__builtin_convertvector(v, bf16x8));   // v_cvt_pk_bf16_f32 (RNE), two values per instruction
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 v = {a[8 * S_ + 2 * i], a[8 * S_ + 2 * i + 1]};
+    const bf16x2 b = __builtin_convertvector(v, bf16x2);
+    const i16x2 zero = {0, 0};
+    r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, b), zero));
+  }
+  return __builtin_bit_cast(bf16x8, r);
 }
 __device__ __forceinline__ void relu_pack(const f32x16& a, bf16x8& s0, bf16x8& s1) {
   s0 = relu_pack_half<0>(a);
