@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--render-frames", type=int, default=3)
     ap.add_argument("--hw", type=int, default=400, help="synthetic image side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-render", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -153,6 +154,35 @@ def main():
               "roofline": {"kernel": "mlp_fwd", "bound": "mfma", "achieved": round(r_ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(r_ach / peak, 4)}}
 
+    # ---- bf16-MFMA render leg (BASELINE configs[4] arithmetic on the same frames; parity bar 1e-2 abs, tests/test_gpu_bf16.py)
+    render_bf16 = None
+    if args.dtype == "f32" and not args.no_bf16_render:
+        rb = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype="bf16")))
+        rb.set_stream(stream)
+        rb.set_params(trainer.get_params())
+        rb.render_dev(ro, rd, bd, rd, n_frame, out)
+        torch.cuda.synchronize(); barrier()
+        rb.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(args.render_frames):
+            rb.render_dev(ro, rd, bd, rd, n_frame, out)
+        torch.cuda.synchronize(); barrier()
+        dtb = time.perf_counter() - t0
+        bprof = rb.get_profile()
+        if world > 1:
+            t = torch.tensor([dtb], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtb = float(t.item())
+        b_ach = bprof["mlp_fwd_flop"] / max(bprof["mlp_fwd_ms"], 1e-9) / 1e9
+        render_bf16 = {"metric": "rays/sec (render, bf16 MFMA)", "value": round(world * n_frame * args.render_frames / dtb, 1),
+                       "unit": "rays/s", "dtype": "bf16", "ms_per_frame": round(1e3 * dtb / args.render_frames, 3),
+                       "roofline": {"kernel": "mlp_fwd_bf16", "bound": "mfma", "achieved": round(b_ach, 2),
+                                    "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                    "frac": round(b_ach / PEAK_TFLOPS["bf16"], 4)},
+                       "hbm_kernels_ms_per_frame": {"composite": round(bprof["composite_ms"] / args.render_frames, 4),
+                                                    "sampling": round(bprof["sampling_ms"] / args.render_frames, 4)}}
+        rb.close()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(base, t_o, t_d, t_b, t_l, args.cpu_seconds)
@@ -167,7 +197,7 @@ def main():
                            "rays_per_gpu_per_step": B, "global_batch": B * world, "samples_per_ray": 192,
                            "parallelism": f"dp{world}"},
                 "samples_per_s": round(train_rays_s * 256, 1),
-                "roofline": roofline, "render": render, "cpu_baseline": cpu}
+                "roofline": roofline, "render": render, "render_bf16": render_bf16, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

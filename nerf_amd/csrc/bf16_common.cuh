@@ -103,19 +103,20 @@ __device__ __forceinline__ f32x16 bias_value(BiasBuf& b) {   // call only behind
 template <int KS, int OT>
 struct PartSched {
   static constexpr int NF = KS * OT;
-  static constexpr int frag_ops(int t) { return t + kPD < NF ? 1 : 0; }
-  static constexpr int bias_ops(int t) { return (t % KS == 0 && t / KS + 1 < OT) ? 4 : 0; }
-  // LDS operations issued behind fragment j's read up to the wait of step j (see file header)
+  static constexpr int kBiasStep = 1;   // k-step of tile ot at which the accumulator-init rows of tile ot+1 are requested
+                                        // (behind the MFMA of step 0 that consumed the single buffer)
+  // LDS operations issued behind the newest operation step j depends on (its fragment; at the first k-step of a
+  // tile also that tile's init rows), up to the wait of step j -- by replaying the issue order:
+  //   prime: init rows of tile 0 (4 reads), fragments 0..min(kPD,NF)-1;  step t: fragment t+kPD, then (t % KS ==
+  //   kBiasStep) init rows of the next tile
   static constexpr int pending(int j) {
-    int n = 0;
-    if (j < kPD) {
-      n = (NF < kPD ? NF : kPD) - 1 - j;   // the prime reads min(kPD, NF) fragments
-      for (int t = 0; t <= j; ++t) n += frag_ops(t) + bias_ops(t);
-    } else {
-      n = bias_ops(j - kPD);
-      for (int t = j - kPD + 1; t <= j; ++t) n += frag_ops(t) + bias_ops(t);
+    int pos = 4, need = (j == 0) ? 4 : 0;
+    for (int f = 0; f < (NF < kPD ? NF : kPD); ++f) { pos += 1; if (f == j) need = pos; }
+    for (int t = 0; t <= j; ++t) {
+      if (t + kPD < NF) { pos += 1; if (t + kPD == j && pos > need) need = pos; }
+      if (t % KS == kBiasStep && t / KS + 1 < OT) { pos += 4; if ((t / KS + 1) * KS == j && pos > need) need = pos; }
     }
-    return n;
+    return pos - need;
   }
   // is the sync point of the block that fragment j lies in executed right after step j?
   static constexpr bool sync_after(int j) { return (j % kBlkFrags == kSyncFrag) || (j == NF - 1 && (j % kBlkFrags) < kSyncFrag); }
@@ -136,18 +137,18 @@ struct EpiPieces {   // runs the pieces of tile OT_IDX scheduled at k-step offse
 template <int KS, int OT, class BSel, class Epi, int J>
 struct PartStep {
   using S = PartSched<KS, OT>;
-  static __device__ __forceinline__ void run(BfRing& rg, int blk0, uint32_t bias_addr, bf16x8 (&fr)[kPD + 1], BiasBuf (&bias)[2],
+  static __device__ __forceinline__ void run(BfRing& rg, int blk0, uint32_t bias_addr, bf16x8 (&fr)[kPD + 1], BiasBuf& bias,
                                              f32x16 (&acc)[2][kNS], const BSel& bsel, Epi& epi) {
     constexpr int ot = J / KS, ks = J % KS;
     if constexpr (J + kPD < S::NF) {
       constexpr int jj = J + kPD;
       lds_read_frag<(jj % kBlkFrags) * 1024>(fr[jj % (kPD + 1)], rg.slot_addr(blk0 + jj / kBlkFrags));
     }
-    if constexpr (ks == 0 && ot + 1 < OT) bias_read<ot + 1>(bias[(ot + 1) & 1], bias_addr);
+    if constexpr (ks == S::kBiasStep && ot + 1 < OT) bias_read<ot + 1>(bias, bias_addr);
     wait_lgkm_n<S::pending(J)>();
     asm volatile("" : "+v"(fr[J % (kPD + 1)]));
     if constexpr (ks == 0) {
-      const f32x16 c0 = bias_value(bias[ot & 1]);
+      const f32x16 c0 = bias_value(bias);
 #pragma unroll
       for (int n = 0; n < kNS; ++n)
         acc[ot & 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[J % (kPD + 1)], bsel.template b<ks>(n), c0, 0, 0, 0);
@@ -167,15 +168,15 @@ struct PartStep {
 // bias_addr: LDS byte address of the part's accumulator-init vector + h*16.
 template <int KS, int OT, class BSel, class Epi>
 __device__ __forceinline__ void run_part(BfRing& rg, uint32_t bias_addr, const BSel& bsel, Epi& epi) {
-  static_assert(KS >= 4 || OT == 1, "bias prefetch needs >= 4 k-steps per output tile");
+  static_assert(KS >= 2 || OT == 1, "the init rows of the next tile are requested at k-step 1");
   static_assert(OT == 1 || piece_offset<KS, Epi::kPieces>(Epi::kPieces - 1) < KS, "epilogue pieces must fit into the next tile");
   using S = PartSched<KS, OT>;
   const int blk0 = rg.blk;
   bf16x8 fr[kPD + 1];
-  BiasBuf bias[2];
+  BiasBuf bias;
   f32x16 acc[2][kNS];
   __builtin_amdgcn_sched_barrier(0);
-  bias_read<0>(bias[0], bias_addr);
+  bias_read<0>(bias, bias_addr);
   lds_read_frag<0>(fr[0], rg.slot_addr(blk0));
   if constexpr (S::NF > 1) lds_read_frag<1024>(fr[1], rg.slot_addr(blk0));
   if constexpr (S::NF > 2) lds_read_frag<2048>(fr[2], rg.slot_addr(blk0));

@@ -20,10 +20,10 @@ struct ActRegs { bf16x8 v[kNS][WT][2]; };
 template <int WT>
 struct SelAct {   // k-steps 0 .. 2WT-1: previous layer; 2WT .. 2WT+3: encoding (skip layers)
   const ActRegs<WT>& a;
-  const ActRegs<2>& e;
+  const ActRegs<2>* e;
   template <int KS_IDX> __device__ __forceinline__ const bf16x8& b(int n) const {
     if constexpr (KS_IDX < 2 * WT) return a.v[n][KS_IDX / 2][KS_IDX % 2];
-    else return e.v[n][(KS_IDX - 2 * WT) / 2][KS_IDX % 2];
+    else return e->v[n][(KS_IDX - 2 * WT) / 2][KS_IDX % 2];
   }
 };
 struct SelEnc {
@@ -35,6 +35,19 @@ struct SelHid {
   const ActRegs<HT>& a;
   template <int KS_IDX> __device__ __forceinline__ const bf16x8& b(int n) const { return a.v[n][KS_IDX / 2][KS_IDX % 2]; }
 };
+template <int H>
+__device__ __forceinline__ void encode_half(ActRegs<2>& enc, const float (&pos)[kNS][3], int E) {
+#pragma unroll
+  for (int n = 0; n < kNS; ++n)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          enc.v[n][kt][s][e] = (__bf16)code_value_fast(pos[n][0], pos[n][1], pos[n][2], 32 * kt + bf_feature(s, H, e), E);
+}
+
 template <int WT>
 struct EpiTrunk {   // relu + bf16 -> B operand of the next layer
   ActRegs<WT>& out;
@@ -45,7 +58,7 @@ struct EpiTrunk {   // relu + bf16 -> B operand of the next layer
 };
 
 struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
-  float* sigma; const int64_t* m; const bool* valid; int h;
+  float* sigma; const int* m; const bool* valid; int h;
   static constexpr int kPieces = 1;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
 #pragma unroll
@@ -56,7 +69,7 @@ struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.sc
 template <int HT, int MODE>
 struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
   ActRegs<HT>& hid; float (&c)[kNS][3];
-  const float* dirfeat; const int64_t* ray; const int64_t* m; const bool* valid; float* sigma; int h;
+  const float* dirfeat; const int* ray; const int* m; const bool* valid; float* sigma; int h;
   static constexpr int kPieces = 1;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
     if constexpr (OT_IDX == HT) {
@@ -67,7 +80,7 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
       // add().relu() (nerfCoreBlock.scala:67): + (Wd.enc(dir) + bd + bf) of the sample's ray, fp32
 #pragma unroll
       for (int n = 0; n < kNS; ++n) {
-        const float* df = dirfeat + ray[n] * (32 * HT) + 32 * OT_IDX + 4 * h;
+        const float* df = dirfeat + (int64_t)ray[n] * (32 * HT) + 32 * OT_IDX + 4 * h;
         f32x16 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -81,7 +94,7 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
       // reshape(...,9,3).mul(SH).sum(-2) (:55): c[k] = sum_j q[3j+k] * Y_j(dir); rows 0..26 of tile 0
 #pragma unroll
       for (int n = 0; n < kNS; ++n) {
-        const float* Y = dirfeat + ray[n] * 12;
+        const float* Y = dirfeat + (int64_t)ray[n] * 12;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = tile_row(0, r, h);
@@ -137,32 +150,35 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
   for (int i = tid; i < nvec; i += 256) vec[i] = bvec[i];
   const uint32_t vec_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)vec + (uint32_t)h * 16u;
 
-  int64_t m[kNS], ray[kNS];
+  int m[kNS], ray[kNS];   // host guarantees M < 2^31
   bool valid[kNS];
-  ActRegs<2> enc;
+  float pos[kNS][3];
 #pragma unroll
   for (int n = 0; n < kNS; ++n) {
-    m[n] = (int64_t)blockIdx.x * kBfTile + wave * (32 * kNS) + n * 32 + li;
-    valid[n] = m[n] < M;
-    const int64_t mc = valid[n] ? m[n] : M - 1;
-    ray[n] = (int64_t)((uint32_t)mc / (uint32_t)S);   // host guarantees M < 2^31
+    m[n] = (int)blockIdx.x * kBfTile + wave * (32 * kNS) + n * 32 + li;
+    valid[n] = m[n] < (int)M;
+    const int mc = valid[n] ? m[n] : (int)M - 1;
+    ray[n] = (int)((uint32_t)mc / (uint32_t)S);
     // sample position (raysO.add(raysD.mul(zVals)), nerfBlock.scala:65): separate mul and add, fp32
     const float zz = z[mc];
-    const float px = __fadd_rn(rays_o[ray[n] * 3 + 0], __fmul_rn(rays_d[ray[n] * 3 + 0], zz));
-    const float py = __fadd_rn(rays_o[ray[n] * 3 + 1], __fmul_rn(rays_d[ray[n] * 3 + 1], zz));
-    const float pz = __fadd_rn(rays_o[ray[n] * 3 + 2], __fmul_rn(rays_d[ray[n] * 3 + 2], zz));
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) enc.v[n][kt][s][e] = (__bf16)code_value_fast(px, py, pz, 32 * kt + bf_feature(s, h, e), net.E);
+    for (int k = 0; k < 3; ++k) pos[n][k] = __fadd_rn(rays_o[(int64_t)ray[n] * 3 + k], __fmul_rn(rays_d[(int64_t)ray[n] * 3 + k], zz));
   }
+  // The encoding (2 k-tiles of B operand) is recomputed where it is needed (layer 0, skip layers) instead of
+  // being kept live through the whole trunk: 3 VALU per value with the hardware sin/cos, and 32 registers less.
+  auto encode = [&](ActRegs<2>& enc) {
+    // the feature a register element holds depends on the lane half only through "+4h": one pass per half with
+    // every index a compile-time constant (3 VALU per value), instead of per-lane index arithmetic
+    if (h == 0) encode_half<0>(enc, pos, net.E);
+    else encode_half<1>(enc, pos, net.E);
+  };
   __syncthreads();   // vectors visible
   rg.start();
 
   ActRegs<WT> act, nxt;
   {
+    ActRegs<2> enc;
+    encode(enc);
     EpiTrunk<WT> epi{act};
     run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
   }
@@ -170,8 +186,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
   auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) {
     EpiTrunk<WT> epi{out};
     const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
-    if ((net.skip_mask >> (l - 1)) & 1u) run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{in, enc}, epi);
-    else run_part<2 * WT, WT>(rg, baddr, SelAct<WT>{in, enc}, epi);
+    if ((net.skip_mask >> (l - 1)) & 1u) {
+      ActRegs<2> enc;
+      encode(enc);
+      run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{in, &enc}, epi);
+    } else {
+      run_part<2 * WT, WT>(rg, baddr, SelAct<WT>{in, nullptr}, epi);
+    }
   };
   int l = 1;
   for (; l + 1 < D; l += 2) {
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
   if (!want_rgb) {
     // sigma-only stream: one tile, row 0 = density row (nerfCoreBlock.scala:39-40)
     EpiSigma epi{sigma, m, valid, h};
-    run_part<2 * WT, 1>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, enc}, epi);
+    run_part<2 * WT, 1>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, nullptr}, epi);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
     return;
   }
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
 #pragma unroll
   for (int n = 0; n < kNS; ++n) c[n][0] = c[n][1] = c[n][2] = 0.f;
   EpiHead<HT, MODE> epih{hid, c, dirfeat, ray, m, valid, sigma, h};
-  run_part<2 * WT, HT + 1>(rg, haddr, SelAct<WT>{act, enc}, epih);
+  run_part<2 * WT, HT + 1>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
 
   if constexpr (MODE == 1) {
     // colour output layer: Linear(3) over the H2 hidden features, as one MFMA tile (rows 0..2)
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 #pragma unroll
   for (int n = 0; n < kNS; ++n)
-    if (valid[n] && h == 0) { craw[m[n] * 3 + 0] = c[n][0]; craw[m[n] * 3 + 1] = c[n][1]; craw[m[n] * 3 + 2] = c[n][2]; }
+    if (valid[n] && h == 0) { craw[(int64_t)m[n] * 3 + 0] = c[n][0]; craw[(int64_t)m[n] * 3 + 1] = c[n][1]; craw[(int64_t)m[n] * 3 + 2] = c[n][2]; }
 }
 
 template <int WT, int MODE>
