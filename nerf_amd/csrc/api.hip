@@ -314,7 +314,8 @@ int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const floa
   if (h->cfg.dtype == NERFHIP_BF16) {
     if (train_store) return fail(h, NERFHIP_E_INVALID, "bf16 training path not built in this version");
     HIPCHK(h, launch_mlp_fwd_bf16(net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z, n.d_dirfeat,
-                                  nr * S, S, sigma, craw, want_rgb ? 1 : 0, h->stream));
+                                  nr * S, S, sigma, craw, want_rgb ? 1 : 0,
+                                  (int)((want_rgb ? n.bf_full.size() : n.bf_sigma.size()) / 32), h->stream));
   } else {
     ActStore st = n.st;
     st.Mpad = (nr * S + kTile - 1) / kTile * kTile;

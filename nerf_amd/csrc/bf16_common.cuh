@@ -4,7 +4,7 @@
 // the sample on the lane, weights as the A operand, fp32 accumulators.  What changes with bf16:
 //   * one MFMA contracts 16 features (lane half h holds 8 consecutive-in-register bf16) and takes 8 passes, i.e.
 //     16x the fp32 rate: the A fragments (1 KiB per wave per MFMA) can no longer come from L2 -- they are staged
-//     through LDS and each fragment is used for NS = 2 sample tiles (a wave owns 64 samples);
+//     through LDS (1 KiB per wave per MFMA = 128 B/clk/CU, half of the LDS read rate);
 //   * the loop is OUTPUT-TILE outer: all K of one 32-row output tile is accumulated before the next tile
 //     starts, so only 2 x NS accumulator tiles are live, the ReLU + bf16 conversion of tile t runs in the shadow
 //     of tile t+1's MFMAs, and the converted tile is directly a B operand of the next layer:
@@ -25,42 +25,50 @@ namespace nh {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kNS = 2;                 // sample tiles (of 32) per wave
-constexpr int kBfTile = 4 * kNS * 32;  // samples per workgroup
+constexpr int kNS = 1;                 // sample tiles (of 32) per wave
+constexpr int kBfWaves = 8;            // waves per workgroup: 2 per SIMD (256 registers each), so one wave's epilogue
+                                       // VALU work and LDS waits hide behind the other's MFMAs
+constexpr int kBfTile = kBfWaves * kNS * 32;  // samples per workgroup
 constexpr int kBlkFrags = 32;
 constexpr int kBlkBytes = kBlkFrags * 1024;
 constexpr int kRing = 4;
-constexpr int kSyncFrag = 28;          // position of the sync point inside a block
-constexpr int kPD = 3;                 // fragments fetched ahead
+constexpr int kPD = 4;                 // fragments fetched ahead
+constexpr int kSyncFrag = kBlkFrags - kPD - 1;   // position of the sync point inside a block (before the prefetch crosses into the next)
 
 // feature (inside a 32-feature tile) held by element e of k-step s in lane half h
 __device__ __host__ constexpr int bf_feature(int s, int h, int e) { return 16 * s + (e & 3) + 8 * (e >> 2) + 4 * h; }
 
+constexpr int kDmaPieces = kBlkBytes / kBfWaves / 1024;   // LDS-DMA instructions per wave per block
 struct BfRing {
-  const char* stream;   // packed fragments (global)
+  const char* stream;   // packed fragments (global), nblk blocks; consumed cyclically (persistent workgroups start
+                        // the next sample tile on block 0 again while the ring keeps running)
   float* ring;          // LDS ring, slot 0
   uint32_t ring_addr;   // LDS byte address of slot 0 + lane*16
-  int blk;              // block being consumed
+  int nblk;             // blocks in the stream
+  int blk;              // consumption counter (never wraps; slot = blk % kRing)
+  int req, req_src;     // request counter (slot = req % kRing) and the stream block it maps to
   int wave, lane;
-  __device__ __forceinline__ void request(int b) const {
-    const char* src = stream + (size_t)b * kBlkBytes + wave * (kBlkBytes / 4) + lane * 16;
-    char* dst = reinterpret_cast<char*>(ring) + (b & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / 4);
+  __device__ __forceinline__ void request() {
+    const char* src = stream + (size_t)req_src * kBlkBytes + wave * (kBlkBytes / kBfWaves) + lane * 16;
+    char* dst = reinterpret_cast<char*>(ring) + (req & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / kBfWaves);
 #pragma unroll
-    for (int p = 0; p < kBlkBytes / 4 / 1024; ++p)
+    for (int p = 0; p < kDmaPieces; ++p)
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + p * 1024), NERFHIP_LPTR(dst + p * 1024), 16, 0, 0);
+    ++req;
+    req_src = req_src + 1 == nblk ? 0 : req_src + 1;
   }
   // kernel prologue: blocks 0..2 requested, block 0 visible
   __device__ __forceinline__ void start() {
-    blk = 0;
-    request(0); request(1); request(2);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    blk = 0; req = 0; req_src = 0;
+    request(); request(); request();
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kDmaPieces) : "memory");
     __builtin_amdgcn_s_barrier();
   }
   // sync point P_blk: block blk+1 visible to every wave, slot of block blk-1 handed to block blk+3
-  __device__ __forceinline__ void sync_point() const {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __device__ __forceinline__ void sync_point() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kDmaPieces) : "memory");
     __builtin_amdgcn_s_barrier();
-    request(blk + 3);
+    request();
   }
   __device__ __forceinline__ uint32_t slot_addr(int b) const { return ring_addr + (uint32_t)(b & (kRing - 1)) * kBlkBytes; }
 };
@@ -164,6 +172,13 @@ struct PartStep {
   }
 };
 
+template <int NF, int F>
+__device__ __forceinline__ void prime_frags_bf(bf16x8 (&fr)[kPD + 1], uint32_t addr) {   // fragments 0..min(kPD,NF)-1
+  if constexpr (F < kPD && F < NF) {
+    lds_read_frag<F * 1024>(fr[F], addr);
+    prime_frags_bf<NF, F + 1>(fr, addr);
+  }
+}
 // Runs one part that starts at block rg.blk (block-aligned) and leaves rg.blk at the next part's first block.
 // bias_addr: LDS byte address of the part's accumulator-init vector + h*16.
 template <int KS, int OT, class BSel, class Epi>
@@ -177,9 +192,7 @@ __device__ __forceinline__ void run_part(BfRing& rg, uint32_t bias_addr, const B
   f32x16 acc[2][kNS];
   __builtin_amdgcn_sched_barrier(0);
   bias_read<0>(bias, bias_addr);
-  lds_read_frag<0>(fr[0], rg.slot_addr(blk0));
-  if constexpr (S::NF > 1) lds_read_frag<1024>(fr[1], rg.slot_addr(blk0));
-  if constexpr (S::NF > 2) lds_read_frag<2048>(fr[2], rg.slot_addr(blk0));
+  prime_frags_bf<S::NF, 0>(fr, rg.slot_addr(blk0));
   PartStep<KS, OT, BSel, Epi, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   wait_lgkm_n<0>();
   __builtin_amdgcn_sched_barrier(0);

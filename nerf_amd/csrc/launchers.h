@@ -46,7 +46,7 @@ hipError_t launch_pack_frags_bf16(const float* params, const FragDesc* descs, in
 hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s);
 hipError_t launch_mlp_fwd_bf16(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                               float* craw, int want_rgb, hipStream_t stream);
+                               float* craw, int want_rgb, int nblk, hipStream_t stream);
 
 // wgrad.hip
 struct WgradItem {

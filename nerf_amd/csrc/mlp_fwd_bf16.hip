@@ -4,12 +4,13 @@
 // accumulation (BASELINE config 5; parity bar: renders within 1e-2 abs of the fp32 path).  Positions, the
 // encoding's sin/cos, biases, the per-ray view-direction branch and all accumulators are fp32; weights and
 // the activations fed to the next layer are rounded to bf16 (RNE).  Machinery: bf16_common.cuh.
-// One wave = 64 samples (2 MFMA sample tiles) x all features; workgroup = 256 samples.
+// One wave = 32 samples x all features; workgroup = 8 waves = 256 samples, persistent (one per CU).
 // Stream layout (api.hip: build_bf16_stream): layer 0 | layers 1..D-1 (skip layers carry 4 extra k-steps for
 // the encoding) | head: HT colour-hidden tiles + one tile whose row 0 is the density row | (mode 1) colour
 // output layer, 1 tile over K = 32 HT.  The sigma-only stream (coarse pass of inference) ends with the density
 // tile alone.
 #include "bf16_common.cuh"
+#include <algorithm>
 #include "launchers.h"
 
 namespace nh {
@@ -123,14 +124,14 @@ struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
 };
 
 template <int WT, int MODE>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const char* __restrict__ stream,
+__global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net, const char* __restrict__ stream,
                                                               const float* __restrict__ bvec,
                                                               const float* __restrict__ rays_o,
                                                               const float* __restrict__ rays_d,
                                                               const float* __restrict__ z,
                                                               const float* __restrict__ dirfeat, int64_t M, int S,
                                                               float* __restrict__ sigma, float* __restrict__ craw,
-                                                              int want_rgb) {
+                                                              int want_rgb, int nblk, int ntiles) {
   constexpr int R = 32 * WT;
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring (kRing x 32 KiB) | vectors
@@ -147,15 +148,22 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
   rg.ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem + (uint32_t)lane * 16u;
   rg.wave = wave;
   rg.lane = lane;
-  for (int i = tid; i < nvec; i += 256) vec[i] = bvec[i];
+  rg.nblk = nblk;
+  for (int i = tid; i < nvec; i += 64 * kBfWaves) vec[i] = bvec[i];
   const uint32_t vec_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)vec + (uint32_t)h * 16u;
 
+  __syncthreads();   // vectors visible
+  rg.start();
+
+  // Persistent: the workgroup walks sample tiles blockIdx.x, +gridDim.x, ...; the weight ring never stops (the
+  // stream is consumed cyclically), so only the first tile pays its start-up latency.
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   int m[kNS], ray[kNS];   // host guarantees M < 2^31
   bool valid[kNS];
   float pos[kNS][3];
 #pragma unroll
   for (int n = 0; n < kNS; ++n) {
-    m[n] = (int)blockIdx.x * kBfTile + wave * (32 * kNS) + n * 32 + li;
+    m[n] = tile * kBfTile + wave * (32 * kNS) + n * 32 + li;
     valid[n] = m[n] < (int)M;
     const int mc = valid[n] ? m[n] : (int)M - 1;
     ray[n] = (int)((uint32_t)mc / (uint32_t)S);
@@ -172,9 +180,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
     if (h == 0) encode_half<0>(enc, pos, net.E);
     else encode_half<1>(enc, pos, net.E);
   };
-  __syncthreads();   // vectors visible
-  rg.start();
-
   ActRegs<WT> act, nxt;
   {
     ActRegs<2> enc;
@@ -187,6 +192,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
     EpiTrunk<WT> epi{out};
     const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
     if ((net.skip_mask >> (l - 1)) & 1u) {
+      // recompute the encoding HERE: made opaque so that it is not hoisted out of the layer loop (it would then be
+      // live -- and spilled -- through the whole trunk)
+#pragma unroll
+      for (int n = 0; n < kNS; ++n) asm volatile("" : "+v"(pos[n][0]), "+v"(pos[n][1]), "+v"(pos[n][2]));
       ActRegs<2> enc;
       encode(enc);
       run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{in, &enc}, epi);
@@ -209,8 +218,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
     // sigma-only stream: one tile, row 0 = density row (nerfCoreBlock.scala:39-40)
     EpiSigma epi{sigma, m, valid, h};
     run_part<2 * WT, 1>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, nullptr}, epi);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
-    return;
+    continue;
   }
 
   // head: HT colour tiles, then the density tile
@@ -231,16 +239,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_bf16_kernel(NetArgs net, const
       c[n][0] += __shfl_xor(c[n][0], 32); c[n][1] += __shfl_xor(c[n][1], 32); c[n][2] += __shfl_xor(c[n][2], 32);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 #pragma unroll
   for (int n = 0; n < kNS; ++n)
     if (valid[n] && h == 0) { craw[(int64_t)m[n] * 3 + 0] = c[n][0]; craw[(int64_t)m[n] * 3 + 1] = c[n][1]; craw[(int64_t)m[n] * 3 + 2] = c[n][2]; }
+  }   // tile loop
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 
 template <int WT, int MODE>
 static hipError_t launch_one(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                              const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                             float* craw, int want_rgb, hipStream_t stream) {
+                             float* craw, int want_rgb, int nblk, hipStream_t stream) {
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   const size_t lds = (size_t)kRing * kBlkBytes + ((size_t)net.D * 32 * WT + (HT + 1) * 32 + 32) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -251,31 +260,38 @@ static hipError_t launch_one(const NetArgs& net, const void* stream_w, const flo
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const dim3 grid((unsigned)((M + kBfTile - 1) / kBfTile)), block(256);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+      n_cu = 256;
+  }
+  const int ntiles = (int)((M + kBfTile - 1) / kBfTile);
+  const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kBfWaves);   // one persistent workgroup per CU
   hipLaunchKernelGGL((mlp_fwd_bf16_kernel<WT, MODE>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
-                     rays_d, z, dirfeat, M, S, sigma, craw, want_rgb);
+                     rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles);
   return hipGetLastError();
 }
 
 template <int WT>
 static hipError_t launch_mode(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                               const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                              float* craw, int want_rgb, hipStream_t stream) {
+                              float* craw, int want_rgb, int nblk, hipStream_t stream) {
   switch (net.mode) {
-    case 1: return launch_one<WT, 1>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
-    case 2: return launch_one<WT, 2>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
-    default: return launch_one<WT, 0>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
+    case 1: return launch_one<WT, 1>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 2: return launch_one<WT, 2>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    default: return launch_one<WT, 0>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
   }
 }
 
 // stream_w: the full stream when want_rgb, else the sigma-only stream (api.hip)
 hipError_t launch_mlp_fwd_bf16(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                               float* craw, int want_rgb, hipStream_t stream) {
+                               float* craw, int want_rgb, int nblk, hipStream_t stream) {
   switch (net.W / 32) {
-    case 2: return launch_mode<2>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
-    case 4: return launch_mode<4>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
-    case 8: return launch_mode<8>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, stream);
+    case 2: return launch_mode<2>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 4: return launch_mode<4>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 8: return launch_mode<8>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
     default: return hipErrorInvalidValue;
   }
 }
