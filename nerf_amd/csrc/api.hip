@@ -40,6 +40,10 @@ struct Net {
   void* d_bf_full = nullptr;
   void* d_bf_sigma = nullptr;
   float* d_bvec = nullptr;
+  std::vector<FragDesc> bf_bwd;                 // backward stream (transposed matrices)
+  FragDesc* d_bf_bwd_desc = nullptr;
+  void* d_bf_bwd = nullptr;
+  BfStore bst{};                                // bf16 training store (allocated on first training call)
   float* d_dirfeat = nullptr;  // [max_rays][max(32*HT, 12)]
   float* d_encdirT = nullptr;  // training, mode 1: [32][Bpad]
   float* d_ddirT = nullptr;    // training, mode 1: d(dirvec)^T [32*HT][Bpad]
@@ -78,6 +82,8 @@ struct nerfhip {
   double* d_loss = nullptr;  // [2]
   bool train_ws = false;
   nh::WgradItem* d_items = nullptr;
+  nh::WgradBfItem* d_bitems = nullptr;   // bf16 path
+  std::vector<nh::WgradBfItem> bitems;
   int32_t* d_items_first = nullptr;   // [n workgroups + 1] first work entry of every persistent workgroup
   std::vector<int32_t> items_first;
   std::vector<nh::WgradItem> items;
@@ -220,6 +226,28 @@ void build_bf16_streams(Net& n) {
   trunk(n.bf_sigma);
   ksteps(n.bf_sigma, L.ws_off, W, 0, 1, 0, W);
   pad(n.bf_sigma);
+
+  // backward stream (mlp_bwd_bf16.hip): element (row = input feature i, k = output feature) = M[k][i]
+  auto tfrag = [&](int64_t off, int ld, int row0, int nrows, int col0, int kvalid, int sidx) {
+    n.bf_bwd.push_back(FragDesc{off, ld, row0, nrows, col0, std::max(0, std::min(32, kvalid)), sidx, 1});
+  };
+  n.bf_bwd.clear();
+  if (L.mode == 1) {   // Wc^T: rows = hidden features, k = colour channel (3)
+    for (int ot = 0; ot < HT; ++ot) tfrag(L.wc_off, L.H2, 32 * ot, L.H2, 0, 3, 0);
+    pad(n.bf_bwd);
+  }
+  for (int ot = 0; ot < WT; ++ot) {   // head: Wf^T (k = head row) then the density k-step (k = 0: w_sigma)
+    for (int kt = 0; kt < HT; ++kt)
+      for (int sidx = 0; sidx < 2; ++sidx) tfrag(L.wf_off, W, 32 * ot, W, 32 * kt, L.head_rows - 32 * kt, sidx);
+    tfrag(L.ws_off, W, 32 * ot, W, 0, 1, 0);
+  }
+  pad(n.bf_bwd);
+  for (int l = L.D - 1; l >= 1; --l) {   // W_l^T restricted to the W activation inputs (the encoding has no gradient)
+    for (int ot = 0; ot < WT; ++ot)
+      for (int kt = 0; kt < WT; ++kt)
+        for (int sidx = 0; sidx < 2; ++sidx) tfrag(L.w_off[l], L.fan_in[l], 32 * ot, W, 32 * kt, 32, sidx);
+    pad(n.bf_bwd);
+  }
 }
 
 NetArgs net_args(const nerfhip* h, const Net& n) {
@@ -290,6 +318,7 @@ int repack(nerfhip* h) {
     if (h->cfg.dtype == NERFHIP_BF16) {
       HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_full_desc, (int)n.bf_full.size(), n.d_bf_full, h->stream));
       HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_sigma_desc, (int)n.bf_sigma.size(), n.d_bf_sigma, h->stream));
+      HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_bwd_desc, (int)n.bf_bwd.size(), n.d_bf_bwd, h->stream));
       HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, h->stream));
     }
   }
@@ -312,8 +341,9 @@ int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const floa
                 float* sigma, float* craw, bool want_rgb) {
   Scope sc(h, P_MLP_FWD);
   if (h->cfg.dtype == NERFHIP_BF16) {
-    if (train_store) return fail(h, NERFHIP_E_INVALID, "bf16 training path not built in this version");
-    HIPCHK(h, launch_mlp_fwd_bf16(net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z, n.d_dirfeat,
+    BfStore bst = n.bst;
+    bst.Mpad = (nr * S + 255) / 256 * 256;
+    HIPCHK(h, launch_mlp_fwd_bf16(train_store ? &bst : nullptr, net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z, n.d_dirfeat,
                                   nr * S, S, sigma, craw, want_rgb ? 1 : 0,
                                   (int)((want_rgb ? n.bf_full.size() : n.bf_sigma.size()) / 32), h->stream));
   } else {
@@ -439,6 +469,7 @@ int check_handle(nerfhip* h) {
 // training path lives in train.hip (same translation-unit-private structs are shared through this header-less
 // include to keep the handle layout in one place)
 #include "train_impl.inc"
+#include "train_bf16.inc"
 
 extern "C" {
 
@@ -531,6 +562,10 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
       CCHK(hipMemsetAsync(n.d_bf_full, 0, (n.bf_full.size() + padf) * 1024, h->stream));
       CCHK(hipMemsetAsync(n.d_bf_sigma, 0, (n.bf_sigma.size() + padf) * 1024, h->stream));
       CCHK(dalloc(&n.d_bvec, (size_t)L.D * L.W + 5 * 32 + 32));
+      CCHK(dalloc(&n.d_bf_bwd_desc, n.bf_bwd.size()));
+      CCHK(hipMemcpy(n.d_bf_bwd_desc, n.bf_bwd.data(), n.bf_bwd.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMalloc(&n.d_bf_bwd, (n.bf_bwd.size() + padf) * 1024));
+      CCHK(hipMemsetAsync(n.d_bf_bwd, 0, (n.bf_bwd.size() + padf) * 1024, h->stream));
     }
     CCHK(dalloc(&n.d_dirfeat, (size_t)h->R * std::max(32 * n.HT, 12)));
   }
@@ -556,10 +591,10 @@ void nerfhip_destroy(nerfhip_t* h) {
   hipSetDevice(h->cfg.device);
   if (h->stream) hipStreamSynchronize(h->stream);
   auto fr = [](void* p) { if (p) hipFree(p); };
-  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first);
+  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
-    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec);
+    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir);
     fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
     fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.st.mask); fr(n.d_dsigma); fr(n.d_dcraw);
   }

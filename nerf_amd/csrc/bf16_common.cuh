@@ -108,7 +108,7 @@ __device__ __forceinline__ f32x16 bias_value(BiasBuf& b) {   // call only behind
 //        the epilogue of a finished output tile, cut into kPieces pieces which are spread over the k-steps of the
 //        NEXT tile (accumulators are double buffered), so its VALU work issues between that tile's MFMAs instead
 //        of stalling on the last MFMA's result with the matrix pipe idle; the last tile's pieces run at the end.
-template <int KS, int OT>
+template <int KS, int OT, bool BIAS = true>
 struct PartSched {
   static constexpr int NF = KS * OT;
   static constexpr int kBiasStep = 1;   // k-step of tile ot at which the accumulator-init rows of tile ot+1 are requested
@@ -118,11 +118,11 @@ struct PartSched {
   //   prime: init rows of tile 0 (4 reads), fragments 0..min(kPD,NF)-1;  step t: fragment t+kPD, then (t % KS ==
   //   kBiasStep) init rows of the next tile
   static constexpr int pending(int j) {
-    int pos = 4, need = (j == 0) ? 4 : 0;
+    int pos = BIAS ? 4 : 0, need = (j == 0) ? pos : 0;
     for (int f = 0; f < (NF < kPD ? NF : kPD); ++f) { pos += 1; if (f == j) need = pos; }
     for (int t = 0; t <= j; ++t) {
       if (t + kPD < NF) { pos += 1; if (t + kPD == j && pos > need) need = pos; }
-      if (t % KS == kBiasStep && t / KS + 1 < OT) { pos += 4; if ((t / KS + 1) * KS == j && pos > need) need = pos; }
+      if (BIAS && t % KS == kBiasStep && t / KS + 1 < OT) { pos += 4; if ((t / KS + 1) * KS == j && pos > need) need = pos; }
     }
     return pos - need;
   }
@@ -142,9 +142,9 @@ struct EpiPieces {   // runs the pieces of tile OT_IDX scheduled at k-step offse
   }
 };
 
-template <int KS, int OT, class BSel, class Epi, int J>
+template <int KS, int OT, class BSel, class Epi, bool BIAS, int J>
 struct PartStep {
-  using S = PartSched<KS, OT>;
+  using S = PartSched<KS, OT, BIAS>;
   static __device__ __forceinline__ void run(BfRing& rg, int blk0, uint32_t bias_addr, bf16x8 (&fr)[kPD + 1], BiasBuf& bias,
                                              f32x16 (&acc)[2][kNS], const BSel& bsel, Epi& epi) {
     constexpr int ot = J / KS, ks = J % KS;
@@ -152,11 +152,16 @@ struct PartStep {
       constexpr int jj = J + kPD;
       lds_read_frag<(jj % kBlkFrags) * 1024>(fr[jj % (kPD + 1)], rg.slot_addr(blk0 + jj / kBlkFrags));
     }
-    if constexpr (ks == S::kBiasStep && ot + 1 < OT) bias_read<ot + 1>(bias, bias_addr);
+    if constexpr (BIAS && ks == S::kBiasStep && ot + 1 < OT) bias_read<ot + 1>(bias, bias_addr);
     wait_lgkm_n<S::pending(J)>();
     asm volatile("" : "+v"(fr[J % (kPD + 1)]));
     if constexpr (ks == 0) {
-      const f32x16 c0 = bias_value(bias);
+      f32x16 c0;
+      if constexpr (BIAS) c0 = bias_value(bias);
+      else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+      }
 #pragma unroll
       for (int n = 0; n < kNS; ++n)
         acc[ot & 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[J % (kPD + 1)], bsel.template b<ks>(n), c0, 0, 0, 0);
@@ -168,7 +173,7 @@ struct PartStep {
     if constexpr (ot >= 1) EpiPieces<KS, Epi, ot - 1, ks>::run(epi, acc[(ot - 1) & 1]);
     if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<KS, Epi, ot, -1>::run(epi, acc[ot & 1]);
     if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkFrags; rg.sync_point(); }
-    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
+    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, BIAS, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   }
 };
 
@@ -181,19 +186,19 @@ __device__ __forceinline__ void prime_frags_bf(bf16x8 (&fr)[kPD + 1], uint32_t a
 }
 // Runs one part that starts at block rg.blk (block-aligned) and leaves rg.blk at the next part's first block.
 // bias_addr: LDS byte address of the part's accumulator-init vector + h*16.
-template <int KS, int OT, class BSel, class Epi>
+template <int KS, int OT, bool BIAS = true, class BSel, class Epi>
 __device__ __forceinline__ void run_part(BfRing& rg, uint32_t bias_addr, const BSel& bsel, Epi& epi) {
-  static_assert(KS >= 2 || OT == 1, "the init rows of the next tile are requested at k-step 1");
+  static_assert(!BIAS || KS >= 2 || OT == 1, "the init rows of the next tile are requested at k-step 1");
   static_assert(OT == 1 || piece_offset<KS, Epi::kPieces>(Epi::kPieces - 1) < KS, "epilogue pieces must fit into the next tile");
-  using S = PartSched<KS, OT>;
+  using S = PartSched<KS, OT, BIAS>;
   const int blk0 = rg.blk;
   bf16x8 fr[kPD + 1];
   BiasBuf bias;
   f32x16 acc[2][kNS];
   __builtin_amdgcn_sched_barrier(0);
-  bias_read<0>(bias, bias_addr);
+  if constexpr (BIAS) bias_read<0>(bias, bias_addr);
   prime_frags_bf<S::NF, 0>(fr, rg.slot_addr(blk0));
-  PartStep<KS, OT, BSel, Epi, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
+  PartStep<KS, OT, BSel, Epi, BIAS, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   wait_lgkm_n<0>();
   __builtin_amdgcn_sched_barrier(0);
   rg.blk = blk0 + (S::NF + kBlkFrags - 1) / kBlkFrags;

@@ -86,6 +86,22 @@ struct ActStore {
                    // word t/2 <-> register r of tile t; lets the backward pass fetch 16 B instead of 512 B per layer
   int64_t Mpad;
 };
+// bf16 training store (cfg.dtype == NERFHIP_BF16).  Every buffer is in MFMA-operand layout: per 32-sample tile
+// and per 32-feature k-tile kt two 1-KiB fragments (k-step s = 0, 1) of [lane = 32h + sample][8 bf16], element e
+// of lane half h holding feature 32kt + bf_feature(s,h,e) (bf16_common.cuh) -- exactly the registers the fused
+// kernels hold, so a wave stores/loads a fragment with ONE 16-byte access per lane, and the bf16 weight-gradient
+// kernel turns it into sample-contiguous MFMA operands with ds_read_b64_tr_b16 (wgrad_bf16.hip).
+//   fragment (tile, kt, s) of a buffer with KT k-tiles: byte offset ((tile*KT + kt)*2 + s) * 1024
+struct BfStore {
+  uint16_t* enc;     // KT = 2            positional encoding
+  uint16_t* act;     // [D] x (KT = W/32) post-ReLU trunk activations (layer l at act + l*W*Mpad elements)
+  uint16_t* hc;      // KT = HT           mode 1: post-ReLU colour hidden layer
+  uint16_t* dy;      // [D] x (KT = W/32) gradients w.r.t. the trunk pre-activations
+  uint16_t* dh;      // KT = HT + 1       head gradients; tile HT: feature 0 = d sigma, 1..3 = d craw
+  uint16_t* encdir;  // KT = 1            mode 1: positionCode(viewdir) of the sample's ray
+  int64_t Mpad;
+};
+
 __host__ __device__ inline int64_t tiled_index(int64_t row, int64_t m, int64_t rows) {
   return ((m >> 5) * rows + row) * 32 + (m & 31);
 }

@@ -44,9 +44,27 @@ hipError_t launch_mlp_bwd_f32(const NetArgs& net, const float* d_sigma, const fl
 // bf16 path
 hipError_t launch_pack_frags_bf16(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s);
 hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s);
-hipError_t launch_mlp_fwd_bf16(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+hipError_t launch_mlp_fwd_bf16(const BfStore* st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
                                float* craw, int want_rgb, int nblk, hipStream_t stream);
+
+hipError_t launch_mlp_bwd_bf16(const BfStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
+                               const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, hipStream_t stream);
+// wgrad_bf16.hip: one slice of the sample axis of one product, operands in the bf16 store's operand layout
+struct WgradBfItem {
+  const uint16_t* A;   // fragment (tile 0, first k-tile of the A rows, s = 0)
+  const uint16_t* B;
+  float* dW;
+  float* db;
+  int64_t a_stride, b_stride;   // bytes per 32-sample tile of the buffers A and B live in
+  int32_t a_rows, b_rows;       // rows (features) of the operands, counted from their first k-tile
+  int32_t a_row0;               // rows of A below a_row0 are not part of the product (dW row = row - a_row0)
+  int32_t ldo, col0;
+  int32_t c0, c1;               // slice of the sample axis in 32-sample tiles
+  int32_t wb_n, shape;          // as WgradItem
+};
+hipError_t launch_wgrad_bf16(const WgradBfItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s);
+hipError_t launch_expand_encdir_bf16(const float* viewdir, int64_t M, int64_t Mpad, int S, int Ed, uint16_t* out, hipStream_t s);
 
 // wgrad.hip
 struct WgradItem {

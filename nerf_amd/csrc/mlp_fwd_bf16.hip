@@ -49,12 +49,19 @@ __device__ __forceinline__ void encode_half(ActRegs<2>& enc, const float (&pos)[
           enc.v[n][kt][s][e] = (__bf16)code_value_fast(pos[n][0], pos[n][1], pos[n][2], 32 * kt + bf_feature(s, H, e), E);
 }
 
-template <int WT>
-struct EpiTrunk {   // relu + bf16 -> B operand of the next layer
+// one 16-byte store per lane: fragment (kt, s) of this wave's sample tile (BfStore layout, common.h)
+__device__ __forceinline__ void store_frag(char* tile_lane, int kt, int s, const bf16x8& v) {
+  *reinterpret_cast<bf16x8*>(tile_lane + (kt * 2 + s) * 1024) = v;
+}
+template <int WT, bool TRAIN>
+struct EpiTrunk {   // relu + bf16 -> B operand of the next layer (TRAIN: also into the activation store)
   ActRegs<WT>& out;
+  char* dst;        // TRAIN: this wave's tile of the layer's activation buffer + lane*16
   static constexpr int kPieces = 2 * kNS;   // (sample tile, k-step half)
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
+    static_assert(kNS == 1, "store addressing assumes one sample tile per wave");
     out.v[P / 2][OT_IDX][P % 2] = relu_pack_half<P % 2>(acc[P / 2]);
+    if constexpr (TRAIN) store_frag(dst, OT_IDX, P % 2, out.v[P / 2][OT_IDX][P % 2]);
   }
 };
 
@@ -67,8 +74,9 @@ struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.sc
       if (valid[n] && h == 0) sigma[m[n]] = acc[n][0];
   }
 };
-template <int HT, int MODE>
+template <int HT, int MODE, bool TRAIN>
 struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
+  char* hc_dst;     // TRAIN, mode 1: this wave's tile of the hc buffer + lane*16
   ActRegs<HT>& hid; float (&c)[kNS][3];
   const float* dirfeat; const int* ray; const int* m; const bool* valid; float* sigma; int h;
   static constexpr int kPieces = 1;
@@ -90,6 +98,7 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
           v[4 * q + 2] = acc[n][4 * q + 2] + d[2]; v[4 * q + 3] = acc[n][4 * q + 3] + d[3];
         }
         relu_pack(v, hid.v[n][OT_IDX][0], hid.v[n][OT_IDX][1]);
+        if constexpr (TRAIN) { store_frag(hc_dst, OT_IDX, 0, hid.v[n][OT_IDX][0]); store_frag(hc_dst, OT_IDX, 1, hid.v[n][OT_IDX][1]); }
       }
     } else if constexpr (MODE == 2) {
       // reshape(...,9,3).mul(SH).sum(-2) (:55): c[k] = sum_j q[3j+k] * Y_j(dir); rows 0..26 of tile 0
@@ -123,7 +132,7 @@ struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
   }
 };
 
-template <int WT, int MODE>
+template <int WT, int MODE, bool TRAIN>
 __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net, const char* __restrict__ stream,
                                                               const float* __restrict__ bvec,
                                                               const float* __restrict__ rays_o,
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
                                                               const float* __restrict__ z,
                                                               const float* __restrict__ dirfeat, int64_t M, int S,
                                                               float* __restrict__ sigma, float* __restrict__ craw,
-                                                              int want_rgb, int nblk, int ntiles) {
+                                                              int want_rgb, int nblk, int ntiles, BfStore st) {
   constexpr int R = 32 * WT;
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring (kRing x 32 KiB) | vectors
@@ -180,16 +189,26 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
     if (h == 0) encode_half<0>(enc, pos, net.E);
     else encode_half<1>(enc, pos, net.E);
   };
+  // TRAIN: this wave's sample tile in the activation store
+  const int64_t tix = (int64_t)tile * kBfWaves + wave;
+  auto tile_lane = [&](uint16_t* buf, int kt_count) {
+    return reinterpret_cast<char*>(buf) + tix * (kt_count * 2048) + lane * 16;
+  };
   ActRegs<WT> act, nxt;
   {
     ActRegs<2> enc;
     encode(enc);
-    EpiTrunk<WT> epi{act};
+    if constexpr (TRAIN) {
+      char* e = tile_lane(st.enc, 2);
+      store_frag(e, 0, 0, enc.v[0][0][0]); store_frag(e, 0, 1, enc.v[0][0][1]);
+      store_frag(e, 1, 0, enc.v[0][1][0]); store_frag(e, 1, 1, enc.v[0][1][1]);
+    }
+    EpiTrunk<WT, TRAIN> epi{act, TRAIN ? tile_lane(st.act, WT) : nullptr};
     run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
   }
   // layers 1..D-1, two per trip (act -> nxt -> act) so the activations never have to be copied
   auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) {
-    EpiTrunk<WT> epi{out};
+    EpiTrunk<WT, TRAIN> epi{out, TRAIN ? tile_lane(st.act + (int64_t)l * R * st.Mpad, WT) : nullptr};
     const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
     if ((net.skip_mask >> (l - 1)) & 1u) {
       // recompute the encoding HERE: made opaque so that it is not hoisted out of the layer loop (it would then be
@@ -226,7 +245,7 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
   float c[kNS][3];
 #pragma unroll
   for (int n = 0; n < kNS; ++n) c[n][0] = c[n][1] = c[n][2] = 0.f;
-  EpiHead<HT, MODE> epih{hid, c, dirfeat, ray, m, valid, sigma, h};
+  EpiHead<HT, MODE, TRAIN> epih{(TRAIN && MODE == 1) ? tile_lane(st.hc, HT) : nullptr, hid, c, dirfeat, ray, m, valid, sigma, h};
   run_part<2 * WT, HT + 1>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
 
   if constexpr (MODE == 1) {
@@ -246,8 +265,8 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 
-template <int WT, int MODE>
-static hipError_t launch_one(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+template <int WT, int MODE, bool TRAIN>
+static hipError_t launch_one(const BfStore& st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                              const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
                              float* craw, int want_rgb, int nblk, hipStream_t stream) {
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
@@ -255,7 +274,7 @@ static hipError_t launch_one(const NetArgs& net, const void* stream_w, const flo
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -268,30 +287,31 @@ static hipError_t launch_one(const NetArgs& net, const void* stream_w, const flo
   }
   const int ntiles = (int)((M + kBfTile - 1) / kBfTile);
   const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kBfWaves);   // one persistent workgroup per CU
-  hipLaunchKernelGGL((mlp_fwd_bf16_kernel<WT, MODE>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
-                     rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles);
+  hipLaunchKernelGGL((mlp_fwd_bf16_kernel<WT, MODE, TRAIN>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
+                     rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles, st);
   return hipGetLastError();
 }
 
 template <int WT>
-static hipError_t launch_mode(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+static hipError_t launch_mode(const BfStore* st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                               const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
                               float* craw, int want_rgb, int nblk, hipStream_t stream) {
   switch (net.mode) {
-    case 1: return launch_one<WT, 1>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
-    case 2: return launch_one<WT, 2>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
-    default: return launch_one<WT, 0>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 1: return st ? launch_one<WT, 1, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream) : launch_one<WT, 1, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 2: return st ? launch_one<WT, 2, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream) : launch_one<WT, 2, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    default: return st ? launch_one<WT, 0, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream) : launch_one<WT, 0, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
   }
 }
 
-// stream_w: the full stream when want_rgb, else the sigma-only stream (api.hip)
-hipError_t launch_mlp_fwd_bf16(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+// stream_w: the full stream when want_rgb, else the sigma-only stream (api.hip); st != nullptr: training forward
+// (activations also go to the bf16 store)
+hipError_t launch_mlp_fwd_bf16(const BfStore* st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
                                float* craw, int want_rgb, int nblk, hipStream_t stream) {
   switch (net.W / 32) {
-    case 2: return launch_mode<2>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
-    case 4: return launch_mode<4>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
-    case 8: return launch_mode<8>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 2: return launch_mode<2>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 4: return launch_mode<4>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 8: return launch_mode<8>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
     default: return hipErrorInvalidValue;
   }
 }

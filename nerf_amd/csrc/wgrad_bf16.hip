@@ -1,0 +1,234 @@
+// wgrad_bf16.hip -- weight-gradient GEMM of the MLP on bf16 MFMA (gfx950), fp32 accumulation and output.
+//
+//   dW[i][j] = sum_m  A[i][m] * B[j][m]          A = dY (gradient rows), B = X (input feature rows)
+// Both operands come from the bf16 training store (common.h: BfStore) in MFMA-operand layout of the FORWARD
+// products, i.e. sample on the lane, 8 features per lane.  This product contracts over the SAMPLE axis, so every
+// fragment is transposed on its way out of LDS with ds_read_b64_tr_b16 (cdna_hip_programming.md T10): within a
+// 16-lane group, lane 4q+p supplies the address of (sample m0+q, features 4p'..4p'+3) -- 8 contiguous bytes of
+// the stored image -- and lane c receives feature c of samples m0..m0+3; two such reads give the 8 consecutive
+// samples (k = 8h .. 8h+7) of one v_mfma_f32_32x32x16_bf16 operand row.
+// Same work decomposition as the fp32 kernel (wgrad.hip): persistent workgroups, one entry = a slice of the sample
+// axis of one product, a <=256x256 output owned by the workgroup in accumulators, the 4 waves arranged 2x2 / 1x4 /
+// 4x1, fp32 atomics into the canonical gradient buffer.  At bf16 MFMA speed the kernel is HBM-bound (one 32-sample
+// chunk of a 256x256 product = 32 KiB of operands for 32 MFMAs per wave), so the staging ring is 4 deep with
+// counted vmcnt waits and the inner loop is kept simple.  Bias gradients (row sums of A) come from one extra MFMA
+// per A fragment against a fragment of ones.
+#include "bf16_common.cuh"
+#include "launchers.h"
+
+namespace nh {
+
+constexpr int kWbStages = 4;
+constexpr int kWbStageBytes = 32 * 1024;      // A tiles (<= 8 x 2 KiB) | B tiles (<= 8 x 2 KiB)
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lds_read_tr(u32x2& d, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d) : "v"(addr));
+}
+__device__ __forceinline__ void wait_vm_dyn(int n) {   // s_waitcnt vmcnt(n), n wave-uniform (smaller = stricter)
+  if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int AT, int BT>
+__device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* smem, int wave, int lane) {
+  const int li = lane & 31, h = lane >> 5;
+  const int wa = wave / it.wb_n, wb = wave - wa * it.wb_n;
+  const int a_tile0 = AT * wa, b_tile0 = BT * wb;          // first 32-row tile of this wave
+  const int a_tiles_all = (it.a_rows + 31) >> 5, b_tiles_all = (it.b_rows + 31) >> 5;
+  const int c0 = it.c0, c1 = it.c1;
+
+  f32x16 acc[AT][BT], accb[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < BT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  const bool do_bias = it.db != nullptr && wb == 0;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  // staging: one stage = the chunk's A tiles (2 KiB each, contiguous in the store) then its B tiles; every wave
+  // issues the same number of 1-KiB pieces per stage (indices past the end repeat the last piece)
+  const int pieces_total = 2 * (a_tiles_all + b_tiles_all);
+  const int P = (pieces_total + 3) >> 2;
+  auto request = [&](int c) {
+    char* dst = smem + ((c - c0) & (kWbStages - 1)) * kWbStageBytes;
+    const char* asrc = reinterpret_cast<const char*>(it.A) + (int64_t)c * it.a_stride;
+    const char* bsrc = reinterpret_cast<const char*>(it.B) + (int64_t)c * it.b_stride;
+    for (int p = 0; p < P; ++p) {
+      int idx = wave + 4 * p;
+      idx = idx < pieces_total ? idx : pieces_total - 1;
+      const bool isb = idx >= 2 * a_tiles_all;
+      const char* src = isb ? bsrc + (idx - 2 * a_tiles_all) * 1024 : asrc + idx * 1024;
+      char* d = dst + (isb ? 16384 + (idx - 2 * a_tiles_all) * 1024 : idx * 1024);
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + lane * 16), NERFHIP_LPTR(d), 16, 0, 0);
+    }
+  };
+  // transposed fragment reads: group g = lane>>4 -> (h = g>>1, k-step s = g&1); lane 4q+p of the group addresses
+  // sample m0+q, feature piece p (lane half p&1, element half p>>1)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const uint32_t lane_tr = (uint32_t)((g & 1) * 1024 + ((p4 & 1) * 32 + 8 * (g >> 1) + q) * 16 + (p4 >> 1) * 8);
+
+  const int n = c1 - c0;
+  request(c0);
+  if (n > 1) request(c0 + 1);
+  if (n > 2) request(c0 + 2);
+  for (int c = c0; c < c1; ++c) {
+    const int ahead = min(c1 - 1 - c, kWbStages - 2);   // stages requested behind this one
+    wait_vm_dyn(ahead * P);
+    __builtin_amdgcn_s_barrier();                        // chunk c visible to all; everyone is done with chunk c-1
+    if (c + 3 < c1) request(c + 3);
+    const uint32_t sbase = lds0 + (uint32_t)(((c - c0) & (kWbStages - 1)) * kWbStageBytes) + lane_tr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {     // samples 16kk .. 16kk+15 of the chunk
+      u32x2 alo[AT], ahi[AT], blo[BT], bhi[BT];
+#pragma unroll
+      for (int i = 0; i < AT; ++i) {
+        const uint32_t a = sbase + (uint32_t)((a_tile0 + i) * 2048 + kk * 256);
+        lds_read_tr(alo[i], a);
+        lds_read_tr(ahi[i], a + 64);
+      }
+#pragma unroll
+      for (int j = 0; j < BT; ++j) {
+        const uint32_t b = sbase + 16384u + (uint32_t)((b_tile0 + j) * 2048 + kk * 256);
+        lds_read_tr(blo[j], b);
+        lds_read_tr(bhi[j], b + 64);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+      for (int i = 0; i < AT; ++i) asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
+#pragma unroll
+      for (int j = 0; j < BT; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+      bf16x8 af[AT], bf[BT];
+#pragma unroll
+      for (int i = 0; i < AT; ++i) { const u32x4 t = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]}; af[i] = __builtin_bit_cast(bf16x8, t); }
+#pragma unroll
+      for (int j = 0; j < BT; ++j) { const u32x4 t = {blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]}; bf[j] = __builtin_bit_cast(bf16x8, t); }
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int j = 0; j < BT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < AT; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
+      }
+    }
+  }
+  // flush: fp32 atomics; rows/cols outside the product (tile padding, rows before a_row0) are dropped
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+      const int col = 32 * (b_tile0 + j) + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * (a_tile0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= it.a_row0 && row < it.a_rows && col < it.b_rows)
+          __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(it.dW + (int64_t)(row - it.a_row0) * it.ldo + it.col0 + col),
+                                 acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (do_bias && li == 0) {   // every column of accb holds the row sums; take column 0
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * (a_tile0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= it.a_row0 && row < it.a_rows)
+          __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(it.db + row - it.a_row0), accb[i][r], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradBfItem* __restrict__ items,
+                                                            const int32_t* __restrict__ first) {
+  extern __shared__ __attribute__((aligned(1024))) char smem_b[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int e0 = first[blockIdx.x], e1 = first[blockIdx.x + 1];
+  for (int e = e0; e < e1; ++e) {
+    const WgradBfItem it = items[e];
+    if (it.c0 >= it.c1) continue;
+    switch (it.shape) {
+      case 0x44: wgrad_bf16_body<4, 4>(it, smem_b, wave, lane); break;
+      case 0x42: wgrad_bf16_body<4, 2>(it, smem_b, wave, lane); break;
+      case 0x41: wgrad_bf16_body<4, 1>(it, smem_b, wave, lane); break;
+      case 0x24: wgrad_bf16_body<2, 4>(it, smem_b, wave, lane); break;
+      case 0x22: wgrad_bf16_body<2, 2>(it, smem_b, wave, lane); break;
+      case 0x21: wgrad_bf16_body<2, 1>(it, smem_b, wave, lane); break;
+      case 0x14: wgrad_bf16_body<1, 4>(it, smem_b, wave, lane); break;
+      case 0x12: wgrad_bf16_body<1, 2>(it, smem_b, wave, lane); break;
+      default:   wgrad_bf16_body<1, 1>(it, smem_b, wave, lane); break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every wave is done with the LDS stages before the next entry requests into them
+  }
+}
+
+// positionCode(viewdir, dirL) of every sample's ray in operand layout (KT = 1): B operand of the Wd gradient
+__global__ __launch_bounds__(256) void expand_encdir_bf16_kernel(const float* __restrict__ viewdir, int64_t M, int S, int Ed,
+                                                                 uint16_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int64_t tix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t m = tix * 32 + li;
+  const bool valid = m < M;
+  const int64_t ray = (valid ? m : M - 1) / S;
+  const float v[3] = {viewdir[ray * 3], viewdir[ray * 3 + 1], viewdir[ray * 3 + 2]};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = bf_feature(s, 0, e) + 4 * h;
+      float x = 0.f;
+      if (valid && f < Ed) {
+        if (f < 3) x = v[f];
+        else {
+          const int k = f - 3, fr = k / 6, rem = k - 6 * fr, c = rem >= 3 ? rem - 3 : rem;
+          const float a = v[c] * (float)(1 << fr);
+          x = rem >= 3 ? cosf(a) : sinf(a);
+        }
+      }
+      t[e] = (__bf16)x;
+    }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(out) + (tix * 2 + s) * 1024 + lane * 16) = t;
+  }
+}
+
+hipError_t launch_wgrad_bf16(const WgradBfItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s) {
+  if (ngroups <= 0) return hipSuccess;
+  const size_t lds = (size_t)kWbStages * kWbStageBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(ngroups), dim3(256), lds, s, d_items, d_first);
+  return hipGetLastError();
+}
+
+// M: real samples; Mpad: samples covered by the store (tiles past M are written as zeros)
+hipError_t launch_expand_encdir_bf16(const float* viewdir, int64_t M, int64_t Mpad, int S, int Ed, uint16_t* out, hipStream_t s) {
+  const int64_t tiles = (Mpad + 31) / 32;
+  hipLaunchKernelGGL(expand_encdir_bf16_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, viewdir, M, S, Ed, out);
+  return hipGetLastError();
+}
+
+}  // namespace nh

@@ -6,15 +6,16 @@ import helpers as H
 from oracle.oracle import Oracle
 from nerf_amd import NerfBlock, NerfConfig
 case = sys.argv[1] if len(sys.argv) > 1 else "small_dir"
+dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
 c = H.CONFIGS[case]
 g = np.load(os.path.join(ROOT, "tests/golden", case + "_train.npz"))
 params = H.make_params(c, int(g["seed"]))
-blk = NerfBlock(NerfConfig.from_dict(dict(c, maxRays=int(g["rays_o"].shape[0]))))
+blk = NerfBlock(NerfConfig.from_dict(dict(c, maxRays=int(g["rays_o"].shape[0]), dtype=dtype)))
 blk.set_params(params)
 rand = {k[5:]: g[k] for k in g.files if k.startswith("rand_")}
 lf, lc = blk.train_backward(g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"], rand=rand or None)
 gr = blk.get_grads()
-rg = g["grads"]
+rg = Oracle(c).train_grads(params, g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"], rand=rand or None)["grads"]
 names = H.layout(c)
 off = 0
 nets = 2 if c["useHierarchical"] else 1

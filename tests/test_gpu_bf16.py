@@ -90,3 +90,69 @@ def test_render_bf16_ragged(G):
     ref = o.forward(params, ro, rd, b, rd, training=False)
     np.testing.assert_allclose(fine, ref["rgb_fine"], rtol=0, atol=1e-2)
     blk.close()
+
+
+def _rand_of(g):
+    return {k[5:]: v for k, v in g.items() if k.startswith("rand_")}
+
+
+@pytest.mark.parametrize("case", ["small_dir_train", "small_sh_train", "small_flat_train", "small_opts_train", "full_train"])
+def test_gradients_bf16(G, case):
+    """d(loss)/d(params) of one batch on the bf16-MFMA training path (bf16 forward, backward-data and weight
+    gradient, fp32 accumulation).  A bf16 network is a (slightly) different function from the fp32 one -- ReLU
+    patterns flip where pre-activations are near zero -- so its gradient legitimately differs from the fp32
+    oracle's by several per cent (the emulation below differs from the oracle by the same amount).  The reference
+    is therefore tests/bf16_ref.py: the golden torch transliteration with every Linear's operands rounded to bf16
+    exactly where the kernels round them.  Whole gradient vector: relative L2 error < 2e-2; every tensor < 1e-1
+    of max(its norm, 5 % of the largest tensor norm) (the deepest layers see the accumulated rounding noise and the
+    hardware sin/cos of the encoding); loss within 1e-2 relative.  Against the fp32 oracle only a
+    sanity bound (< 0.3)."""
+    import bf16_ref
+    name = case.rsplit("_", 1)[0]
+    c = H.CONFIGS[name]
+    g = load(case)
+    params = H.make_params(c, int(g["seed"]))
+    rand = _rand_of(g)
+    blk = G.make_block(c, dtype="bf16")
+    blk.set_params(params)
+    lf, lc = blk.train_backward(g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"], rand=rand)
+    gr = blk.get_grads()
+    rlf, rlc, rg = bf16_ref.train_grads(c, params, g["rays_o"], g["rays_d"], g["bounds"], g["label"], rand)
+    assert np.isfinite(gr).all()
+    assert lf == pytest.approx(rlf, rel=1e-2)
+    if c["useHierarchical"]:
+        assert lc == pytest.approx(rlc, rel=1e-2)
+    assert np.linalg.norm(gr - rg) / np.linalg.norm(rg) < 2e-2
+    off = 0
+    spans = []
+    for _ in range(2 if c["useHierarchical"] else 1):
+        for nm, r_, c_ in H.layout(c):
+            spans.append((nm, off, r_ * c_)); off += r_ * c_
+    big = max(np.linalg.norm(rg[o_:o_ + k]) for _, o_, k in spans)
+    for nm, o_, k in spans:
+        a, b = gr[o_:o_ + k], rg[o_:o_ + k]
+        assert np.linalg.norm(a - b) <= 1e-1 * max(np.linalg.norm(b), 0.05 * big), nm
+    og = Oracle(c).train_grads(params, g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"], rand=rand)["grads"]
+    assert np.linalg.norm(gr - og) / np.linalg.norm(og) < 0.3
+    blk.close()
+
+
+def test_psnr_after_fixed_steps_bf16(G):
+    """North-star criterion on the bf16 path: PSNR after 40 Adam steps within 0.1 dB of the fp32 reference path."""
+    c = H.cfg(D=4, W=64, skips=[1], posL=6, dirL=2, NSamples=32, NImportance=32, lrate=2e-3)
+    o = Oracle(c)
+    n = 256
+    ro, rd, b, _ = H.make_rays(n, 31)
+    label = (0.5 + 0.5 * np.sin(3 * rd + ro)).astype(np.float32)
+    params = H.make_params(c, 5, bias_scale=0.0)
+    blk = G.make_block(c, max_rays=n, dtype="bf16")
+    blk.set_params(params)
+    p = params.copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+    first = o.train_grads(params, ro, rd, b, rd, label)["loss_fine"]
+    for t in range(1, 41):
+        lf_g, lc_g = blk.train_step(ro, rd, b, rd, label)
+        r = o.train_grads(p, ro, rd, b, rd, label)
+        o.adam(p, r["grads"], m, v, t)
+    assert lf_g < 0.8 * first
+    assert abs(-10 * np.log10(lf_g) + 10 * np.log10(r["loss_fine"])) < 0.1, (lf_g, r["loss_fine"])
+    blk.close()
