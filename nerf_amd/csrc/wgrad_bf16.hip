@@ -11,8 +11,8 @@
 // axis of one product, a <=256x256 output owned by the workgroup in accumulators, the 4 waves arranged 2x2 / 1x4 /
 // 4x1, fp32 atomics into the canonical gradient buffer.  At bf16 MFMA speed the kernel is HBM-bound (one 32-sample
 // chunk of a 256x256 product = 32 KiB of operands for 32 MFMAs per wave), so the staging ring is 4 deep with
-// counted vmcnt waits and the inner loop is kept simple.  Bias gradients (row sums of A) come from one extra MFMA
-// per A fragment against a fragment of ones.
+// counted vmcnt waits, and the staged image is swizzled (wb_slot) so the transposed reads are bank-conflict free.
+// Bias gradients (row sums of A) are v_dot2_f32_bf16 sums over the A fragments a wave holds anyway.
 #include "bf16_common.cuh"
 #include "launchers.h"
 
@@ -21,11 +21,10 @@ namespace nh {
 constexpr int kWbStages = 4;
 constexpr int kWbStageBytes = 32 * 1024;      // A tiles (<= 8 x 2 KiB) | B tiles (<= 8 x 2 KiB)
 
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char lds_char;
 
-__device__ __forceinline__ void lds_read_tr(u32x2& d, uint32_t addr) {
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d) : "v"(addr));
-}
 __device__ __forceinline__ void wait_vm_dyn(int n) {   // s_waitcnt vmcnt(n), n wave-uniform (smaller = stricter)
   if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -40,6 +39,15 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {   // s_waitcnt vmcnt(n), n 
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// LDS image of one staged fragment (64 lanes x 16 B, lane = 32*hp + sample): the 16-byte slot of (hp, sample m) is
+//   32*hp + (m & 16) + ((m + 8*s + 4*hp) & 15),   s = the fragment's k-step
+// so that the 32 eight-byte pieces one half-wave fetches in a transposed read (2 k-steps x 2 lane halves x 4
+// samples x 2 element halves) fall into 32 different bank pairs; the linear image has them 4 deep on 8 pairs.
+__device__ __forceinline__ int wb_slot(int s, int hp, int m) { return 32 * hp + (m & 16) + ((m + 8 * s + 4 * hp) & 15); }
+
+template <int N>
+struct WbOps { bf16x8 v[N]; };
+
 template <int AT, int BT>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* smem, int wave, int lane) {
   const int li = lane & 31, h = lane >> 5;
@@ -48,27 +56,27 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
   const int a_tiles_all = (it.a_rows + 31) >> 5, b_tiles_all = (it.b_rows + 31) >> 5;
   const int c0 = it.c0, c1 = it.c1;
 
-  f32x16 acc[AT][BT], accb[AT];
+  f32x16 acc[AT][BT];
+  float bsum[AT];
 #pragma unroll
   for (int i = 0; i < AT; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    bsum[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < BT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
   const bool do_bias = it.db != nullptr && wb == 0;
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
   // staging: one stage = the chunk's A tiles (2 KiB each, contiguous in the store) then its B tiles; every wave
-  // issues the same number of 1-KiB pieces per stage (indices past the end repeat the last piece)
+  // issues the same number of 1-KiB pieces per stage (indices past the end repeat the last piece).  LDS slot
+  // `lane` of a piece takes the source lane that wb_slot() maps there.
   const int pieces_total = 2 * (a_tiles_all + b_tiles_all);
   const int P = (pieces_total + 3) >> 2;
-  auto request = [&](int c) {
-    char* dst = smem + ((c - c0) & (kWbStages - 1)) * kWbStageBytes;
+  const int src_lane0 = (32 * h + (li & 16) + (((li & 15) - 4 * h) & 15)) * 16;        // pieces of k-step 0
+  const int src_lane1 = (32 * h + (li & 16) + (((li & 15) - 8 - 4 * h) & 15)) * 16;    // pieces of k-step 1
+  auto request = [&](int c, int slot) {   // chunk c into ring stage slot & 3
+    char* dst = smem + (slot & (kWbStages - 1)) * kWbStageBytes;
     const char* asrc = reinterpret_cast<const char*>(it.A) + (int64_t)c * it.a_stride;
     const char* bsrc = reinterpret_cast<const char*>(it.B) + (int64_t)c * it.b_stride;
     for (int p = 0; p < P; ++p) {
@@ -77,60 +85,74 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
       const bool isb = idx >= 2 * a_tiles_all;
       const char* src = isb ? bsrc + (idx - 2 * a_tiles_all) * 1024 : asrc + idx * 1024;
       char* d = dst + (isb ? 16384 + (idx - 2 * a_tiles_all) * 1024 : idx * 1024);
-      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + lane * 16), NERFHIP_LPTR(d), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + ((idx & 1) ? src_lane1 : src_lane0)), NERFHIP_LPTR(d), 16, 0, 0);
     }
   };
-  // transposed fragment reads: group g = lane>>4 -> (h = g>>1, k-step s = g&1); lane 4q+p of the group addresses
-  // sample m0+q, feature piece p (lane half p&1, element half p>>1)
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
-  const uint32_t lane_tr = (uint32_t)((g & 1) * 1024 + ((p4 & 1) * 32 + 8 * (g >> 1) + q) * 16 + (p4 >> 1) * 8);
-
-  const int n = c1 - c0;
-  request(c0);
-  if (n > 1) request(c0 + 1);
-  if (n > 2) request(c0 + 2);
-  for (int c = c0; c < c1; ++c) {
-    const int ahead = min(c1 - 1 - c, kWbStages - 2);   // stages requested behind this one
-    wait_vm_dyn(ahead * P);
-    __builtin_amdgcn_s_barrier();                        // chunk c visible to all; everyone is done with chunk c-1
-    if (c + 3 < c1) request(c + 3);
-    const uint32_t sbase = lds0 + (uint32_t)(((c - c0) & (kWbStages - 1)) * kWbStageBytes) + lane_tr;
+  // transposed fragment reads: group g = lane>>4 -> (sample half hg = g>>1, k-step s = g&1); lane 4q+p of the
+  // group addresses sample 16kk + 8hg + 4hi + q, feature piece p (lane half hp = p&1, element half p>>1)
+  lds_char* const lds0 = (lds_char*)smem;
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tr_off0 = (tg & 1) * 1024 + wb_slot(tg & 1, tp & 1, 8 * (tg >> 1) + tq) * 16 + (tp >> 1) * 8;       // samples +0..3
+  const int tr_off1 = (tg & 1) * 1024 + wb_slot(tg & 1, tp & 1, 8 * (tg >> 1) + 4 + tq) * 16 + (tp >> 1) * 8;   // samples +4..7
+  auto read_ops = [&](int c, int kk, WbOps<AT>& a, WbOps<BT>& b) {
+    lds_char* const st = lds0 + ((c - c0) & (kWbStages - 1)) * kWbStageBytes + kk * 256;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {     // samples 16kk .. 16kk+15 of the chunk
-      u32x2 alo[AT], ahi[AT], blo[BT], bhi[BT];
+    for (int i = 0; i < AT; ++i) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + (a_tile0 + i) * 2048 + tr_off0));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + (a_tile0 + i) * 2048 + tr_off1));
+      const short __attribute__((ext_vector_type(8))) t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      a.v[i] = __builtin_bit_cast(bf16x8, t);
+    }
 #pragma unroll
-      for (int i = 0; i < AT; ++i) {
-        const uint32_t a = sbase + (uint32_t)((a_tile0 + i) * 2048 + kk * 256);
-        lds_read_tr(alo[i], a);
-        lds_read_tr(ahi[i], a + 64);
-      }
+    for (int j = 0; j < BT; ++j) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + 16384 + (b_tile0 + j) * 2048 + tr_off0));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + 16384 + (b_tile0 + j) * 2048 + tr_off1));
+      const short __attribute__((ext_vector_type(8))) t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      b.v[j] = __builtin_bit_cast(bf16x8, t);
+    }
+  };
+  const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
+  auto mma = [&](const WbOps<AT>& a, const WbOps<BT>& b) {
 #pragma unroll
-      for (int j = 0; j < BT; ++j) {
-        const uint32_t b = sbase + 16384u + (uint32_t)((b_tile0 + j) * 2048 + kk * 256);
-        lds_read_tr(blo[j], b);
-        lds_read_tr(bhi[j], b + 64);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)");
+    for (int i = 0; i < AT; ++i)
 #pragma unroll
-      for (int i = 0; i < AT; ++i) asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
-#pragma unroll
-      for (int j = 0; j < BT; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
-      bf16x8 af[AT], bf[BT];
-#pragma unroll
-      for (int i = 0; i < AT; ++i) { const u32x4 t = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]}; af[i] = __builtin_bit_cast(bf16x8, t); }
-#pragma unroll
-      for (int j = 0; j < BT; ++j) { const u32x4 t = {blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]}; bf[j] = __builtin_bit_cast(bf16x8, t); }
+      for (int j = 0; j < BT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[i], b.v[j], acc[i][j], 0, 0, 0);
+    if (do_bias) {   // row sums of A: this lane's 8 samples of row li
 #pragma unroll
       for (int i = 0; i < AT; ++i)
 #pragma unroll
-        for (int j = 0; j < BT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < AT; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
-      }
+        for (int e = 0; e < 4; ++e) {
+          const bf16x2 pr = {a.v[i][2 * e], a.v[i][2 * e + 1]};
+          bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, bsum[i], false);
+        }
     }
+  };
+
+  // chunk c+1's first half is fetched from LDS under the MFMAs of chunk c's second half, chunk c's second half
+  // under its first: the LDS latency is hidden without a second wave per SIMD
+  // Requests past the entry's last chunk repeat that chunk (into a stage nobody reads), which keeps the number of
+  // outstanding pieces -- and with it every wait count -- the same in every iteration.
+  const int cl = c1 - 1;
+  request(c0, 0);
+  request(min(c0 + 1, cl), 1);
+  request(min(c0 + 2, cl), 2);
+  wait_vm_dyn(2 * P);
+  __builtin_amdgcn_s_barrier();
+  WbOps<AT> a0, a1;
+  WbOps<BT> b0, b1;
+  read_ops(c0, 0, a0, b0);
+  for (int c = c0; c < cl; ++c) {
+    read_ops(c, 1, a1, b1);
+    mma(a0, b0);
+    wait_vm_dyn(P);                          // chunk c+1 has landed (c+2 may still be in flight)
+    __builtin_amdgcn_s_barrier();            // ... for every wave; every wave is done reading chunk c-1
+    request(min(c + 3, cl), c + 3 - c0);     // into the stage chunk c-1 used
+    read_ops(c + 1, 0, a0, b0);
+    mma(a1, b1);
   }
+  read_ops(cl, 1, a1, b1);
+  mma(a0, b0);
+  mma(a1, b1);
   // flush: fp32 atomics; rows/cols outside the product (tile padding, rows before a_row0) are dropped
 #pragma unroll
   for (int i = 0; i < AT; ++i) {
@@ -145,14 +167,11 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
                                  acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (do_bias && li == 0) {   // every column of accb holds the row sums; take column 0
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * (a_tile0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= it.a_row0 && row < it.a_rows)
-          __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(it.db + row - it.a_row0), accb[i][r], __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-      }
+    if (do_bias) {   // both lane halves hold a partial sum of row li
+      const int row = 32 * (a_tile0 + i) + li;
+      if (row >= it.a_row0 && row < it.a_rows)
+        __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(it.db + row - it.a_row0), bsum[i], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
