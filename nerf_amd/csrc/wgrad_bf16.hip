@@ -45,16 +45,21 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {   // s_waitcnt vmcnt(n), n 
 // samples x 2 element halves) fall into 32 different bank pairs; the linear image has them 4 deep on 8 pairs.
 __device__ __forceinline__ int wb_slot(int s, int hp, int m) { return 32 * hp + (m & 16) + ((m + 8 * s + 4 * hp) & 15); }
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int N>
 struct WbOps { bf16x8 v[N]; };
+template <int N>
+struct WbRaw { u32x2 lo[N], hi[N]; };   // destinations of transposed reads in flight
 
-template <int AT, int BT>
+// PW: staging pieces (1 KiB each) a wave issues per chunk -- 4 or 8; a wave with fewer real pieces re-issues its
+// last one (same source, same destination), so that every wait count is a compile-time constant.
+template <int AT, int BT, int PW>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* smem, int wave, int lane) {
   const int li = lane & 31, h = lane >> 5;
   const int wa = wave / it.wb_n, wb = wave - wa * it.wb_n;
   const int a_tile0 = AT * wa, b_tile0 = BT * wb;          // first 32-row tile of this wave
   const int a_tiles_all = (it.a_rows + 31) >> 5, b_tiles_all = (it.b_rows + 31) >> 5;
-  const int c0 = it.c0, c1 = it.c1;
+  const int c0 = it.c0, c1 = it.c1, cl = c1 - 1;
 
   f32x16 acc[AT][BT];
   float bsum[AT];
@@ -66,48 +71,72 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
-  const bool do_bias = it.db != nullptr && wb == 0;
+  // the waves that share an A tile split its bias sums: tile i belongs to the wave with wb == i mod wb_n
+  bool do_bias[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) do_bias[i] = it.db != nullptr && (i & (it.wb_n - 1)) == wb;
 
-  // staging: one stage = the chunk's A tiles (2 KiB each, contiguous in the store) then its B tiles; every wave
-  // issues the same number of 1-KiB pieces per stage (indices past the end repeat the last piece).  LDS slot
-  // `lane` of a piece takes the source lane that wb_slot() maps there.
+  // staging: one stage = the chunk's A tiles (2 KiB each, contiguous in the store) then its B tiles, piece idx of
+  // the stage = wave + 4p.  Per piece: a running source pointer, its stride per chunk and its offset in the stage.
   const int pieces_total = 2 * (a_tiles_all + b_tiles_all);
-  const int P = (pieces_total + 3) >> 2;
-  const int src_lane0 = (32 * h + (li & 16) + (((li & 15) - 4 * h) & 15)) * 16;        // pieces of k-step 0
-  const int src_lane1 = (32 * h + (li & 16) + (((li & 15) - 8 - 4 * h) & 15)) * 16;    // pieces of k-step 1
-  auto request = [&](int c, int slot) {   // chunk c into ring stage slot & 3
-    char* dst = smem + (slot & (kWbStages - 1)) * kWbStageBytes;
-    const char* asrc = reinterpret_cast<const char*>(it.A) + (int64_t)c * it.a_stride;
-    const char* bsrc = reinterpret_cast<const char*>(it.B) + (int64_t)c * it.b_stride;
-    for (int p = 0; p < P; ++p) {
-      int idx = wave + 4 * p;
-      idx = idx < pieces_total ? idx : pieces_total - 1;
-      const bool isb = idx >= 2 * a_tiles_all;
-      const char* src = isb ? bsrc + (idx - 2 * a_tiles_all) * 1024 : asrc + idx * 1024;
-      char* d = dst + (isb ? 16384 + (idx - 2 * a_tiles_all) * 1024 : idx * 1024);
-      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + ((idx & 1) ? src_lane1 : src_lane0)), NERFHIP_LPTR(d), 16, 0, 0);
-    }
+  const int idx_last = wave + 4 * ((pieces_total - 1 - wave) >> 2);    // pieces_total >= 4: every wave has one
+  const char* pptr[PW];
+  uint32_t pstr[PW], pdst[PW];
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int idx = min(wave + 4 * p, idx_last);
+    const bool isb = idx >= 2 * a_tiles_all;
+    const int k = isb ? idx - 2 * a_tiles_all : idx;
+    pstr[p] = (uint32_t)(isb ? it.b_stride : it.a_stride);
+    pptr[p] = reinterpret_cast<const char*>(isb ? it.B : it.A) + (int64_t)c0 * pstr[p] + k * 1024;
+    pdst[p] = (isb ? 16384u : 0u) + (uint32_t)k * 1024u;
+  }
+  // LDS slot `lane` of a piece takes the source lane that wb_slot() maps there; the k-step of every piece of this
+  // wave is wave & 1
+  const uint32_t src_lane = (uint32_t)(32 * h + (li & 16) + (((li & 15) - 8 * (wave & 1) - 4 * h) & 15)) * 16u;
+  // piece p of chunk min(r, cl) into ring stage (r - c0) & 3; called with consecutive r for every piece
+  auto issue = [&](int p, int r) {
+    char* d = smem + ((r - c0) & (kWbStages - 1)) * kWbStageBytes + pdst[p];
+    __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(pptr[p] + src_lane), NERFHIP_LPTR(d), 16, 0, 0);
+    pptr[p] += r < cl ? pstr[p] : 0u;
   };
   // transposed fragment reads: group g = lane>>4 -> (sample half hg = g>>1, k-step s = g&1); lane 4q+p of the
-  // group addresses sample 16kk + 8hg + 4hi + q, feature piece p (lane half hp = p&1, element half p>>1)
-  lds_char* const lds0 = (lds_char*)smem;
+  // group addresses sample 16kk + 8hg + 4hi + q, feature piece p (lane half hp = p&1, element half p>>1).
+  // Inline asm, because the compiler orders every LDS read it knows of behind ALL outstanding LDS-DMA (vmcnt(0)),
+  // which would serialise the staging ring; the reads are landed by land_ops() before their registers are used
+  // (scripts/check_inflight.py verifies that on the final ISA).
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
   const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-  const int tr_off0 = (tg & 1) * 1024 + wb_slot(tg & 1, tp & 1, 8 * (tg >> 1) + tq) * 16 + (tp >> 1) * 8;       // samples +0..3
-  const int tr_off1 = (tg & 1) * 1024 + wb_slot(tg & 1, tp & 1, 8 * (tg >> 1) + 4 + tq) * 16 + (tp >> 1) * 8;   // samples +4..7
-  auto read_ops = [&](int c, int kk, WbOps<AT>& a, WbOps<BT>& b) {
-    lds_char* const st = lds0 + ((c - c0) & (kWbStages - 1)) * kWbStageBytes + kk * 256;
+  const uint32_t tr_off0 = (uint32_t)((tg & 1) * 1024 + wb_slot(tg & 1, tp & 1, 8 * (tg >> 1) + tq) * 16 + (tp >> 1) * 8);       // samples +0..3
+  const uint32_t tr_off1 = (uint32_t)((tg & 1) * 1024 + wb_slot(tg & 1, tp & 1, 8 * (tg >> 1) + 4 + tq) * 16 + (tp >> 1) * 8);   // samples +4..7
+  const uint32_t a_off0 = lds0 + tr_off0 + a_tile0 * 2048, a_off1 = lds0 + tr_off1 + a_tile0 * 2048;
+  const uint32_t b_off0 = lds0 + tr_off0 + 16384 + b_tile0 * 2048, b_off1 = lds0 + tr_off1 + 16384 + b_tile0 * 2048;
+  auto read_ops = [&](int c, int kk, WbRaw<AT>& a, WbRaw<BT>& b) {
+    const uint32_t st = (uint32_t)(((c - c0) & (kWbStages - 1)) * kWbStageBytes + kk * 256);
+    const uint32_t a0v = a_off0 + st, a1v = a_off1 + st, b0v = b_off0 + st, b1v = b_off1 + st;
 #pragma unroll
     for (int i = 0; i < AT; ++i) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + (a_tile0 + i) * 2048 + tr_off0));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + (a_tile0 + i) * 2048 + tr_off1));
-      const short __attribute__((ext_vector_type(8))) t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.lo[i]) : "v"(a0v), "n"(i * 2048));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.hi[i]) : "v"(a1v), "n"(i * 2048));
+    }
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b.lo[j]) : "v"(b0v), "n"(j * 2048));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b.hi[j]) : "v"(b1v), "n"(j * 2048));
+    }
+  };
+  auto land_ops = [&](WbRaw<AT>& ra, WbRaw<BT>& rb, WbOps<AT>& a, WbOps<BT>& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < AT; ++i) {
+      asm volatile("" : "+v"(ra.lo[i]), "+v"(ra.hi[i]));
+      const u32x4 t = {ra.lo[i][0], ra.lo[i][1], ra.hi[i][0], ra.hi[i][1]};
       a.v[i] = __builtin_bit_cast(bf16x8, t);
     }
 #pragma unroll
     for (int j = 0; j < BT; ++j) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + 16384 + (b_tile0 + j) * 2048 + tr_off0));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + 16384 + (b_tile0 + j) * 2048 + tr_off1));
-      const short __attribute__((ext_vector_type(8))) t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      asm volatile("" : "+v"(rb.lo[j]), "+v"(rb.hi[j]));
+      const u32x4 t = {rb.lo[j][0], rb.lo[j][1], rb.hi[j][0], rb.hi[j][1]};
       b.v[j] = __builtin_bit_cast(bf16x8, t);
     }
   };
@@ -117,41 +146,52 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
     for (int i = 0; i < AT; ++i)
 #pragma unroll
       for (int j = 0; j < BT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[i], b.v[j], acc[i][j], 0, 0, 0);
-    if (do_bias) {   // row sums of A: this lane's 8 samples of row li
 #pragma unroll
-      for (int i = 0; i < AT; ++i)
+    for (int i = 0; i < AT; ++i)
+      if (do_bias[i]) {   // row sums of A: this lane's 8 samples of row li
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bf16x2 pr = {a.v[i][2 * e], a.v[i][2 * e + 1]};
           bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, bsum[i], false);
         }
-    }
+      }
   };
 
-  // chunk c+1's first half is fetched from LDS under the MFMAs of chunk c's second half, chunk c's second half
-  // under its first: the LDS latency is hidden without a second wave per SIMD
-  // Requests past the entry's last chunk repeat that chunk (into a stage nobody reads), which keeps the number of
-  // outstanding pieces -- and with it every wait count -- the same in every iteration.
-  const int cl = c1 - 1;
-  request(c0, 0);
-  request(min(c0 + 1, cl), 1);
-  request(min(c0 + 2, cl), 2);
-  wait_vm_dyn(2 * P);
+  // Software pipeline, in half-chunks of 16 samples: the MFMAs of one half run while the next half's operands are
+  // fetched from LDS and half of the pieces of the chunk three ahead are issued.  Mid-chunk: wait for chunk c+1
+  // (everything but the PW pieces of chunk c+2 has landed), barrier, and the stage of chunk c-1 is free for c+3.
+  constexpr int PH = PW / 2;
+#pragma unroll
+  for (int p = 0; p < PW; ++p) issue(p, c0);
+#pragma unroll
+  for (int p = 0; p < PW; ++p) issue(p, c0 + 1);
+#pragma unroll
+  for (int p = 0; p < PH; ++p) issue(p, c0 + 2);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + PH) : "memory");
   __builtin_amdgcn_s_barrier();
+  WbRaw<AT> ra0, ra1;
+  WbRaw<BT> rb0, rb1;
   WbOps<AT> a0, a1;
   WbOps<BT> b0, b1;
-  read_ops(c0, 0, a0, b0);
-  for (int c = c0; c < cl; ++c) {
-    read_ops(c, 1, a1, b1);
+  read_ops(c0, 0, ra0, rb0);
+  land_ops(ra0, rb0, a0, b0);
+  for (int c = c0; c < cl; ++c) {   // no read is in flight across the back edge (its registers could be copied)
+    read_ops(c, 1, ra1, rb1);
+#pragma unroll
+    for (int p = PH; p < PW; ++p) issue(p, c + 2);
     mma(a0, b0);
-    wait_vm_dyn(P);                          // chunk c+1 has landed (c+2 may still be in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // chunk c+1 has landed (c+2 may be in flight)
     __builtin_amdgcn_s_barrier();            // ... for every wave; every wave is done reading chunk c-1
-    request(min(c + 3, cl), c + 3 - c0);     // into the stage chunk c-1 used
-    read_ops(c + 1, 0, a0, b0);
+    land_ops(ra1, rb1, a1, b1);
+    read_ops(c + 1, 0, ra0, rb0);
+#pragma unroll
+    for (int p = 0; p < PH; ++p) issue(p, c + 3);   // into the stage chunk c-1 used
     mma(a1, b1);
+    land_ops(ra0, rb0, a0, b0);
   }
-  read_ops(cl, 1, a1, b1);
+  read_ops(cl, 1, ra1, rb1);
   mma(a0, b0);
+  land_ops(ra1, rb1, a1, b1);
   mma(a1, b1);
   // flush: fp32 atomics; rows/cols outside the product (tile padding, rows before a_row0) are dropped
 #pragma unroll
@@ -167,7 +207,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
                                  acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (do_bias) {   // both lane halves hold a partial sum of row li
+    if (do_bias[i]) {   // both lane halves hold a partial sum of row li
       const int row = 32 * (a_tile0 + i) + li;
       if (row >= it.a_row0 && row < it.a_rows)
         __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(it.db + row - it.a_row0), bsum[i], __ATOMIC_RELAXED,
@@ -184,16 +224,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradBfItem* _
   for (int e = e0; e < e1; ++e) {
     const WgradBfItem it = items[e];
     if (it.c0 >= it.c1) continue;
-    switch (it.shape) {
-      case 0x44: wgrad_bf16_body<4, 4>(it, smem_b, wave, lane); break;
-      case 0x42: wgrad_bf16_body<4, 2>(it, smem_b, wave, lane); break;
-      case 0x41: wgrad_bf16_body<4, 1>(it, smem_b, wave, lane); break;
-      case 0x24: wgrad_bf16_body<2, 4>(it, smem_b, wave, lane); break;
-      case 0x22: wgrad_bf16_body<2, 2>(it, smem_b, wave, lane); break;
-      case 0x21: wgrad_bf16_body<2, 1>(it, smem_b, wave, lane); break;
-      case 0x14: wgrad_bf16_body<1, 4>(it, smem_b, wave, lane); break;
-      case 0x12: wgrad_bf16_body<1, 2>(it, smem_b, wave, lane); break;
-      default:   wgrad_bf16_body<1, 1>(it, smem_b, wave, lane); break;
+    const int pieces = 2 * (((it.a_rows + 31) >> 5) + ((it.b_rows + 31) >> 5));
+    switch (it.shape | (pieces > 16 ? 0x100 : 0)) {
+      case 0x144: wgrad_bf16_body<4, 4, 8>(it, smem_b, wave, lane); break;
+      case 0x142: wgrad_bf16_body<4, 2, 8>(it, smem_b, wave, lane); break;
+      case 0x141: wgrad_bf16_body<4, 1, 8>(it, smem_b, wave, lane); break;
+      case 0x124: wgrad_bf16_body<2, 4, 8>(it, smem_b, wave, lane); break;
+      case 0x114: wgrad_bf16_body<1, 4, 8>(it, smem_b, wave, lane); break;
+      case 0x112: wgrad_bf16_body<1, 2, 8>(it, smem_b, wave, lane); break;
+      case 0x121: wgrad_bf16_body<2, 1, 8>(it, smem_b, wave, lane); break;
+      case 0x042: wgrad_bf16_body<4, 2, 4>(it, smem_b, wave, lane); break;
+      case 0x041: wgrad_bf16_body<4, 1, 4>(it, smem_b, wave, lane); break;
+      case 0x024: wgrad_bf16_body<2, 4, 4>(it, smem_b, wave, lane); break;
+      case 0x022: wgrad_bf16_body<2, 2, 4>(it, smem_b, wave, lane); break;
+      case 0x021: wgrad_bf16_body<2, 1, 4>(it, smem_b, wave, lane); break;
+      case 0x014: wgrad_bf16_body<1, 4, 4>(it, smem_b, wave, lane); break;
+      case 0x012: wgrad_bf16_body<1, 2, 4>(it, smem_b, wave, lane); break;
+      case 0x011: wgrad_bf16_body<1, 1, 4>(it, smem_b, wave, lane); break;
+      default:    wgrad_bf16_body<2, 2, 8>(it, smem_b, wave, lane); break;   // 0x122 (and nothing else: see add_items_bf16)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // every wave is done with the LDS stages before the next entry requests into them
