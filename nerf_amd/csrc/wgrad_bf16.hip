@@ -18,7 +18,8 @@
 
 namespace nh {
 
-constexpr int kWbStages = 4;
+constexpr int kWbStages = 5;                  // 5 x 32 KiB = the CU's whole LDS
+constexpr int kWbAhead = kWbStages - 2;       // whole chunks in flight behind the one being waited for
 constexpr int kWbStageBytes = 32 * 1024;      // A tiles (<= 8 x 2 KiB) | B tiles (<= 8 x 2 KiB)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -96,7 +97,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
   const uint32_t src_lane = (uint32_t)(32 * h + (li & 16) + (((li & 15) - 8 * (wave & 1) - 4 * h) & 15)) * 16u;
   // piece p of chunk min(r, cl) into ring stage (r - c0) & 3; called with consecutive r for every piece
   auto issue = [&](int p, int r) {
-    char* d = smem + ((r - c0) & (kWbStages - 1)) * kWbStageBytes + pdst[p];
+    char* d = smem + (uint32_t)(r - c0) % (uint32_t)kWbStages * kWbStageBytes + pdst[p];
     __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(pptr[p] + src_lane), NERFHIP_LPTR(d), 16, 0, 0);
     pptr[p] += r < cl ? pstr[p] : 0u;
   };
@@ -112,7 +113,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
   const uint32_t a_off0 = lds0 + tr_off0 + a_tile0 * 2048, a_off1 = lds0 + tr_off1 + a_tile0 * 2048;
   const uint32_t b_off0 = lds0 + tr_off0 + 16384 + b_tile0 * 2048, b_off1 = lds0 + tr_off1 + 16384 + b_tile0 * 2048;
   auto read_ops = [&](int c, int kk, WbRaw<AT>& a, WbRaw<BT>& b) {
-    const uint32_t st = (uint32_t)(((c - c0) & (kWbStages - 1)) * kWbStageBytes + kk * 256);
+    const uint32_t st = (uint32_t)(c - c0) % (uint32_t)kWbStages * kWbStageBytes + kk * 256;
     const uint32_t a0v = a_off0 + st, a1v = a_off1 + st, b0v = b_off0 + st, b1v = b_off1 + st;
 #pragma unroll
     for (int i = 0; i < AT; ++i) {
@@ -158,16 +159,16 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
   };
 
   // Software pipeline, in half-chunks of 16 samples: the MFMAs of one half run while the next half's operands are
-  // fetched from LDS and half of the pieces of the chunk three ahead are issued.  Mid-chunk: wait for chunk c+1
-  // (everything but the PW pieces of chunk c+2 has landed), barrier, and the stage of chunk c-1 is free for c+3.
+  // fetched from LDS and half of the pieces of a chunk kWbAhead(+1) ahead are issued.  Mid-chunk: wait for chunk c+1
+  // (all but the chunks behind it have landed), barrier, and the stage of chunk c-1 is free for c+kWbAhead+1.
   constexpr int PH = PW / 2;
 #pragma unroll
-  for (int p = 0; p < PW; ++p) issue(p, c0);
+  for (int r = 0; r < kWbAhead; ++r)
 #pragma unroll
-  for (int p = 0; p < PW; ++p) issue(p, c0 + 1);
+    for (int p = 0; p < PW; ++p) issue(p, c0 + r);
 #pragma unroll
-  for (int p = 0; p < PH; ++p) issue(p, c0 + 2);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + PH) : "memory");
+  for (int p = 0; p < PH; ++p) issue(p, c0 + kWbAhead);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kWbAhead - 1) * PW + PH) : "memory");
   __builtin_amdgcn_s_barrier();
   WbRaw<AT> ra0, ra1;
   WbRaw<BT> rb0, rb1;
@@ -178,14 +179,14 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
   for (int c = c0; c < cl; ++c) {   // no read is in flight across the back edge (its registers could be copied)
     read_ops(c, 1, ra1, rb1);
 #pragma unroll
-    for (int p = PH; p < PW; ++p) issue(p, c + 2);
+    for (int p = PH; p < PW; ++p) issue(p, c + kWbAhead);
     mma(a0, b0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // chunk c+1 has landed (c+2 may be in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kWbAhead - 1) * PW) : "memory");   // chunk c+1 has landed
     __builtin_amdgcn_s_barrier();            // ... for every wave; every wave is done reading chunk c-1
     land_ops(ra1, rb1, a1, b1);
     read_ops(c + 1, 0, ra0, rb0);
 #pragma unroll
-    for (int p = 0; p < PH; ++p) issue(p, c + 3);   // into the stage chunk c-1 used
+    for (int p = 0; p < PH; ++p) issue(p, c + kWbAhead + 1);   // into the stage chunk c-1 used
     mma(a1, b1);
     land_ops(ra0, rb0, a0, b0);
   }
