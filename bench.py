@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--hw", type=int, default=400, help="synthetic image side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-render", action="store_true")
+    ap.add_argument("--no-bf16-train", action="store_true", help="skip the bf16 training legs (same batch; config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -183,6 +184,89 @@ def main():
                                                     "sampling": round(bprof["sampling_ms"] / args.render_frames, 4)}}
         rb.close()
 
+    # ---- bf16-MFMA training legs: the same batch (configs[3] arithmetic in bf16), and BASELINE configs[4]:
+    # 1024x1024 forward-facing scene, NDC rays (llff.scala:96-132), 64 + 256 samples per ray
+    def timed_train(blk, o_, d_, b_, l_, nsteps):
+        g = grad_tensor(blk) if world > 1 else None
+
+        def one():
+            if world == 1:
+                blk.train_step_dev(o_, d_, b_, d_, l_, B)
+            else:
+                blk.train_backward_dev(o_, d_, b_, d_, l_, B)
+                dist.all_reduce(g)
+                blk.optimizer_step(1.0 / world)
+        for _ in range(args.warmup):
+            one()
+        torch.cuda.synchronize(); barrier()
+        blk.set_profiling(True)
+        t0_ = time.perf_counter()
+        for _ in range(nsteps):
+            one()
+        torch.cuda.synchronize(); barrier()
+        d_t = time.perf_counter() - t0_
+        pr = blk.get_profile()
+        blk.set_profiling(False)
+        if world > 1:
+            t_ = torch.tensor([d_t], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            d_t = float(t_.item())
+        ks = {"mlp_fwd": (pr["mlp_fwd_ms"], pr["mlp_fwd_flop"]), "mlp_bwd": (pr["mlp_bwd_ms"], pr["mlp_bwd_flop"]),
+              "mlp_wgrad": (pr["mlp_wgrad_ms"], pr["mlp_wgrad_flop"])}
+        return {"value": round(world * B * nsteps / d_t, 1), "unit": "rays/s", "dtype": "bf16", "steps": nsteps,
+                "ms_per_step": round(1e3 * d_t / nsteps, 3),
+                "kernel_ms_per_step": {k: round(v[0] / nsteps, 4) for k, v in ks.items()},
+                "kernel_tflops": {k: round(v[1] / max(v[0], 1e-9) / 1e9, 1) for k, v in ks.items()}}
+
+    train_bf16 = config5 = None
+    if args.dtype == "f32" and not args.no_bf16_train:
+        tb = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=B, dtype="bf16")))
+        tb.set_stream(stream)
+        tb.init_params(7)
+        train_bf16 = timed_train(tb, t_o, t_d, t_b, t_l, args.steps)
+        train_bf16["metric"] = "rays/sec (train step, bf16 MFMA)"
+        tb.close()
+        # config 5
+        HW5 = 1024
+        n5 = HW5 * HW5
+        c5 = dict(base, NImportance=256, dtype="bf16")
+        t5 = NerfBlock(NerfConfig.from_dict(dict(c5, maxRays=B)))
+        r5 = NerfBlock(NerfConfig.from_dict(dict(c5, maxRays=n5 // 4)))
+        t5.set_stream(stream); r5.set_stream(stream)
+        t5.init_params(7)
+        ro5, rd5, bd5 = torch.empty(n5, 3, **f32), torch.empty(n5, 3, **f32), torch.empty(n5, 2, **f32)
+        c2w5 = np.array([[1, 0, 0, 0.05 * rank], [0, 1, 0, 0.02], [0, 0, 1, 0.1]], np.float32)
+        r5.k_gen_rays(HW5, HW5, 0.9 * HW5, c2w5, 0.0, 1.0, True, ro5, rd5, bd5)
+        torch.cuda.synchronize()
+        lab5 = 0.5 + 0.5 * torch.sin(3.0 * rd5 + ro5)
+        idx5 = torch.randperm(n5, generator=gsel)[:B].cuda()
+        config5 = timed_train(t5, ro5[idx5].contiguous(), rd5[idx5].contiguous(), bd5[idx5].contiguous(),
+                              lab5[idx5].contiguous(), args.steps)
+        r5.set_params(t5.get_params())
+        out5 = torch.empty(n5, 3, **f32)
+        q = n5 // 4
+
+        def frame5():
+            for k in range(4):   # a 1024x1024 frame in four 256-row blocks (workspace sized for one block)
+                sl = slice(k * q, (k + 1) * q)
+                r5.render_dev(ro5[sl], rd5[sl], bd5[sl], rd5[sl], q, out5[sl])
+        frame5()
+        torch.cuda.synchronize(); barrier()
+        t0 = time.perf_counter()
+        frame5()
+        torch.cuda.synchronize(); barrier()
+        dt5 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt5], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt5 = float(t.item())
+        config5.update({"metric": "rays/sec (train step, bf16 MFMA, config 5)",
+                        "workload": "1024x1024 forward-facing scene, NDC rays, 64+256 samples/ray, 8x256 MLP",
+                        "samples_per_ray": 320,
+                        "render": {"value": round(world * n5 / dt5, 1), "unit": "rays/s", "ms_per_frame": round(1e3 * dt5, 2),
+                                   "frames": 1}})
+        t5.close(); r5.close()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(base, t_o, t_d, t_b, t_l, args.cpu_seconds)
@@ -197,7 +281,8 @@ def main():
                            "rays_per_gpu_per_step": B, "global_batch": B * world, "samples_per_ray": 192,
                            "parallelism": f"dp{world}"},
                 "samples_per_s": round(train_rays_s * 256, 1),
-                "roofline": roofline, "render": render, "render_bf16": render_bf16, "cpu_baseline": cpu}
+                "roofline": roofline, "render": render, "render_bf16": render_bf16, "train_bf16": train_bf16,
+                "config5_bf16": config5, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

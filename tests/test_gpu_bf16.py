@@ -156,3 +156,32 @@ def test_psnr_after_fixed_steps_bf16(G):
     assert lf_g < 0.8 * first
     assert abs(-10 * np.log10(lf_g) + 10 * np.log10(r["loss_fine"])) < 0.1, (lf_g, r["loss_fine"])
     blk.close()
+
+
+@pytest.mark.parametrize("dtype,atol", [("f32", 2e-4), ("bf16", 1e-2)])
+def test_config5_ndc_rays_256_fine_samples(G, dtype, atol):
+    """BASELINE configs[4] in small: forward-facing NDC rays (llff.scala:96-132, getDataSet.scala:112 bounds
+    (0, |d'|)) generated on the device, full 8x256 network with 64 + 256 samples per ray (S_fine = 320), against
+    the oracle on the same rays.  Ray generation is bit-exact; fp32 render as in test_gpu_render, bf16 within 1e-2."""
+    import torch
+    c = dict(H.CONFIGS["full"], NImportance=256)
+    o = Oracle(c)
+    Hh, Ww, f = 12, 20, 18.0
+    c2w = np.array([[1, 0, 0, 0.1], [0, 1, 0, -0.05], [0, 0, 1, 0.2]], np.float32)
+    n = Hh * Ww
+    blk = G.make_block(c, dtype=dtype)
+    ro, rd, b = G.empty(n, 3), G.empty(n, 3), G.empty(n, 2)
+    blk.k_gen_rays(Hh, Ww, f, c2w, 0.0, 1.0, True, ro, rd, b)
+    blk.synchronize()
+    eo, ed, eb = o.gen_rays(Hh, Ww, f, c2w, 0.0, 1.0, True)
+    np.testing.assert_array_equal(ro.cpu().numpy(), eo)
+    np.testing.assert_array_equal(rd.cpu().numpy(), ed)
+    np.testing.assert_array_equal(b.cpu().numpy(), eb)
+    params = H.make_params(c, 5)
+    blk.set_params(params)
+    fine, _, dbg = blk.forward(eo, ed, eb, ed, training=False, debug=True)
+    ref = o.forward(params, eo, ed, eb, ed, training=False)
+    assert dbg["z_fine"].shape == (n, 320)
+    np.testing.assert_array_equal(dbg["z_coarse"], ref["z_coarse"])
+    np.testing.assert_allclose(fine, ref["rgb_fine"], rtol=0, atol=atol)
+    blk.close()
