@@ -594,7 +594,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
-    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir);
+    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
     fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
     fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.st.mask); fr(n.d_dsigma); fr(n.d_dcraw);
   }

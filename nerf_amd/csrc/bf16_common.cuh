@@ -39,6 +39,21 @@ constexpr int kSyncFrag = kBlkFrags - kPD - 1;   // position of the sync point i
 __device__ __host__ constexpr int bf_feature(int s, int h, int e) { return 16 * s + (e & 3) + 8 * (e >> 2) + 4 * h; }
 
 constexpr int kDmaPieces = kBlkBytes / kBfWaves / 1024;   // LDS-DMA instructions per wave per block
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n >= 4 (rounded down to a supported count: stricter, never weaker)
+__device__ __forceinline__ void wait_vm_at_most(int n) {
+  if (n >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+  else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+}
+
 struct BfRing {
   const char* stream;   // packed fragments (global), nblk blocks; consumed cyclically (persistent workgroups start
                         // the next sample tile on block 0 again while the ring keeps running)
@@ -48,27 +63,39 @@ struct BfRing {
   int blk;              // consumption counter (never wraps; slot = blk % kRing)
   int req, req_src;     // request counter (slot = req % kRing) and the stream block it maps to
   int wave, lane;
+  // vmcnt retires in order, so "block blk+1 has landed" = "at most Y operations outstanding", Y = the VMEM
+  // operations this wave issued behind that block's pieces: the pieces of block blk+2 plus the activation stores /
+  // mask loads of the training kernels, which note() counts (young_a: between the requests of blocks blk+1 and
+  // blk+2, young_b: since).  Counting them lets those stay in flight across sync points; an operation that is not
+  // noted only makes the wait stricter.  Every noted operation must be exactly >= 1 VMEM instruction.
+  int young_a, young_b;
+  __device__ __forceinline__ void note(int n) { young_b += n; }
   __device__ __forceinline__ void request() {
     const char* src = stream + (size_t)req_src * kBlkBytes + wave * (kBlkBytes / kBfWaves) + lane * 16;
     char* dst = reinterpret_cast<char*>(ring) + (req & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / kBfWaves);
 #pragma unroll
     for (int p = 0; p < kDmaPieces; ++p)
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + p * 1024), NERFHIP_LPTR(dst + p * 1024), 16, 0, 0);
+    asm volatile("" ::: "memory");   // no later memory operation may be issued in front of the pieces
     ++req;
     req_src = req_src + 1 == nblk ? 0 : req_src + 1;
   }
   // kernel prologue: blocks 0..2 requested, block 0 visible
   __device__ __forceinline__ void start() {
     blk = 0; req = 0; req_src = 0;
+    asm volatile("" ::: "memory");
     request(); request(); request();
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kDmaPieces) : "memory");
     __builtin_amdgcn_s_barrier();
+    young_a = young_b = 0;
   }
   // sync point P_blk: block blk+1 visible to every wave, slot of block blk-1 handed to block blk+3
   __device__ __forceinline__ void sync_point() {
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kDmaPieces) : "memory");
+    wait_vm_at_most(young_a + kDmaPieces + young_b);
     __builtin_amdgcn_s_barrier();
     request();
+    young_a = young_b;
+    young_b = 0;
   }
   __device__ __forceinline__ uint32_t slot_addr(int b) const { return ring_addr + (uint32_t)(b & (kRing - 1)) * kBlkBytes; }
 };
@@ -231,6 +258,33 @@ __device__ __forceinline__ bf16x8 relu_pack_half(const f32x16& a) {
     r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, b), zero));
   }
   return __builtin_bit_cast(bf16x8, r);
+}
+// ReLU' bits of a trunk layer, 16 B per lane (lane = sample li, half h, as everywhere): word ot>>1, bit
+//   8 (ot & 1) + 4 s + i  (+16 for the odd element)   <->  output tile ot, k-step s, elements 2i / 2i+1
+// of the fragment, i.e. feature 32 ot + bf_feature(s, h, 2i [+1]).  The forward kernel gathers them from the packed
+// post-ReLU pairs (non-zero <=> positive), the backward kernel expands them into 16-bit AND masks.
+template <int OT_IDX, int S_>
+__device__ __forceinline__ void relu_bits_gather(u32x4& words, const bf16x8& act) {
+  typedef unsigned short u16x2_ __attribute__((ext_vector_type(2)));
+  const u32x4 r = __builtin_bit_cast(u32x4, act);
+  const u16x2_ one = {1, 1};
+  unsigned d = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned x = r[i];   // (a bit_cast of the vector ELEMENT expression r[i] reads element 0 with this clang)
+    d |= __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2_, x), one)) << i;
+  }
+  words[OT_IDX >> 1] |= d << (8 * (OT_IDX & 1) + 4 * S_);
+}
+template <int OT_IDX, int S_>
+__device__ __forceinline__ u32x4 relu_bits_expand(const u32x4& words) {
+  u32x4 m;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned t = (words[OT_IDX >> 1] >> (8 * (OT_IDX & 1) + 4 * S_ + i)) & 0x00010001u;
+    m[i] = t * 0xffffu;                  // 0/1 per half -> 0x0000/0xffff per half
+  }
+  return m;
 }
 __device__ __forceinline__ void relu_pack(const f32x16& a, bf16x8& s0, bf16x8& s1) {
   s0 = relu_pack_half<0>(a);

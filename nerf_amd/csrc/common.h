@@ -99,6 +99,8 @@ struct BfStore {
   uint16_t* dy;      // [D] x (KT = W/32) gradients w.r.t. the trunk pre-activations
   uint16_t* dh;      // KT = HT + 1       head gradients; tile HT: feature 0 = d sigma, 1..3 = d craw
   uint16_t* encdir;  // KT = 1            mode 1: positionCode(viewdir) of the sample's ray
+  uint32_t* relu;    // [D] x 16 B per lane of every 32-sample tile: ReLU' bits of the trunk layers (bf16_common.cuh:
+                     // relu_bits), layer l at relu + l*Mpad*8 words
   int64_t Mpad;
 };
 

@@ -67,13 +67,38 @@ struct EpiGrad {
   GradRegs<NT>& out;
   const char* act;   // stored post-ReLU activations of that layer, this wave's tile + lane*16
   char* dst;         // gradient store, this wave's tile + lane*16
+  BfRing& rg;
   bf16x8 mk[2][2];
   static constexpr int kPieces = 2;
-  __device__ __forceinline__ void prefetch(int ot) { mk[ot & 1][0] = load_frag(act, ot, 0); mk[ot & 1][1] = load_frag(act, ot, 1); }
+  __device__ __forceinline__ void prefetch(int ot) { mk[ot & 1][0] = load_frag(act, ot, 0); mk[ot & 1][1] = load_frag(act, ot, 1); rg.note(2); }
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
     if constexpr (P == 0 && OT_IDX + 1 < NT) prefetch(OT_IDX + 1);
     out.v[0][OT_IDX][P] = mask_pack_half<P>(acc[0], mk[OT_IDX & 1][P]);
     store_frag_b(dst, OT_IDX, P, out.v[0][OT_IDX][P]);
+    rg.note(1);
+  }
+};
+
+// the same for a trunk layer, masked by the ReLU' bits the forward kernel stored (16 B per lane per layer, fetched
+// a whole layer ahead -- the stored activations themselves are only read by the weight-gradient kernel)
+template <int NT>
+struct EpiGradBits {
+  GradRegs<NT>& out;
+  char* dst;          // gradient store, this wave's tile + lane*16
+  BfRing& rg;
+  const u32x4& bits;
+  static constexpr int kPieces = 2;
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 v = {acc[0][8 * P + 2 * i], acc[0][8 * P + 2 * i + 1]};
+      r[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    }
+    const u32x4 m = relu_bits_expand<OT_IDX, P>(bits);
+    out.v[0][OT_IDX][P] = __builtin_bit_cast(bf16x8, r & m);
+    store_frag_b(dst, OT_IDX, P, out.v[0][OT_IDX][P]);
+    rg.note(1);
   }
 };
 
@@ -101,6 +126,11 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_bwd_bf16_kernel(NetArgs net
   rg.nblk = nblk;
   rg.start();
 
+  auto bits_lane = [&](int l, int64_t tix_) {   // a lane's 16 B of layer l's ReLU' bits (BfStore::relu)
+    return reinterpret_cast<const u32x4*>(st.relu + (int64_t)l * st.Mpad * 8) + tix_ * 64 + lane;
+  };
+  u32x4 bitsA = {0u, 0u, 0u, 0u}, bitsB = bitsA, bitsN = bitsA;
+  if ((int)blockIdx.x < ntiles) bitsA = *bits_lane(D - 1, (int64_t)blockIdx.x * kBfWaves + wave);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m = tile * kBfTile + wave * 32 + li;
     const bool valid = m < (int)M;
@@ -133,7 +163,7 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_bwd_bf16_kernel(NetArgs net
     // ---- d(head pre-activation)
     GradRegs<HT> dh;
     if constexpr (MODE == 1) {
-      EpiGrad<HT> epi{dh, tile_lane(st.hc, HT), dh_dst, {}};
+      EpiGrad<HT> epi{dh, tile_lane(st.hc, HT), dh_dst, rg, {}};
       epi.prefetch(0);
       run_part<1, HT, false>(rg, 0u, SelOne{dcol}, epi);   // Wc^T . d craw, masked by the colour hidden layer's ReLU
     } else {
@@ -156,24 +186,31 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_bwd_bf16_kernel(NetArgs net
     }
 
     // ---- head backward: d feat = Wf^T . dh + w_sigma . d sigma, masked by the last trunk layer's ReLU
+    // ReLU' bits: the part that produces dY_k uses bits k and fetches bits k-1 (the last part: the next sample
+    // tile's bits D-1), alternating between two register sets
+    const int64_t tnext = (int64_t)(tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile) * kBfWaves + wave;
     GradRegs<WT> g, gn;
     {
-      EpiGrad<WT> epi{g, tile_lane(st.act + (int64_t)(D - 1) * R * st.Mpad, WT), tile_lane(st.dy + (int64_t)(D - 1) * R * st.Mpad, WT), {}};
-      epi.prefetch(0);
+      if (D >= 2) { bitsB = *bits_lane(D - 2, tix); rg.note(1); }
+      else { bitsN = *bits_lane(D - 1, tnext); rg.note(1); }
+      EpiGradBits<WT> epi{g, tile_lane(st.dy + (int64_t)(D - 1) * R * st.Mpad, WT), rg, bitsA};
       run_part<2 * HT + 1, WT, false>(rg, 0u, SelHead<HT>{dh, dsig}, epi);
     }
     // ---- trunk, last layer first: dY_{l-1} = ReLU'_{l-1} . (W_l^T . dY_l); two layers per trip (g -> gn -> g)
-    auto layer = [&](int l, const GradRegs<WT>& in, GradRegs<WT>& out) {
-      EpiGrad<WT> epi{out, tile_lane(st.act + (int64_t)(l - 1) * R * st.Mpad, WT), tile_lane(st.dy + (int64_t)(l - 1) * R * st.Mpad, WT), {}};
-      epi.prefetch(0);
+    auto layer = [&](int l, const GradRegs<WT>& in, GradRegs<WT>& out, const u32x4& use, u32x4& fetch) {
+      if (l >= 2) fetch = *bits_lane(l - 2, tix);
+      else bitsN = *bits_lane(D - 1, tnext);
+      rg.note(1);
+      EpiGradBits<WT> epi{out, tile_lane(st.dy + (int64_t)(l - 1) * R * st.Mpad, WT), rg, use};
       run_part<2 * WT, WT, false>(rg, 0u, SelGrad<WT>{in}, epi);
     };
     int l = D - 1;
     for (; l >= 2; l -= 2) {
-      layer(l, g, gn);
-      layer(l - 1, gn, g);
+      layer(l, g, gn, bitsB, bitsA);
+      layer(l - 1, gn, g, bitsA, bitsB);
     }
-    if (l >= 1) layer(l, g, gn);
+    if (l >= 1) layer(l, g, gn, bitsB, bitsA);
+    bitsA = bitsN;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }

@@ -57,11 +57,19 @@ template <int WT, bool TRAIN>
 struct EpiTrunk {   // relu + bf16 -> B operand of the next layer (TRAIN: also into the activation store)
   ActRegs<WT>& out;
   char* dst;        // TRAIN: this wave's tile of the layer's activation buffer + lane*16
+  u32x4* bits_dst;  // TRAIN: this lane's 16 B of the layer's ReLU' bits
+  BfRing& rg;
+  u32x4 bits;
   static constexpr int kPieces = 2 * kNS;   // (sample tile, k-step half)
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
     static_assert(kNS == 1, "store addressing assumes one sample tile per wave");
     out.v[P / 2][OT_IDX][P % 2] = relu_pack_half<P % 2>(acc[P / 2]);
-    if constexpr (TRAIN) store_frag(dst, OT_IDX, P % 2, out.v[P / 2][OT_IDX][P % 2]);
+    if constexpr (TRAIN) {
+      store_frag(dst, OT_IDX, P % 2, out.v[P / 2][OT_IDX][P % 2]);
+      rg.note(1);
+      relu_bits_gather<OT_IDX, P % 2>(bits, out.v[P / 2][OT_IDX][P % 2]);
+      if constexpr (OT_IDX == WT - 1 && P == kPieces - 1) { *bits_dst = bits; rg.note(1); }
+    }
   }
 };
 
@@ -194,6 +202,9 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
   auto tile_lane = [&](uint16_t* buf, int kt_count) {
     return reinterpret_cast<char*>(buf) + tix * (kt_count * 2048) + lane * 16;
   };
+  auto bits_lane = [&](int l) {   // this lane's 16 B of layer l's ReLU' bits (BfStore::relu)
+    return reinterpret_cast<u32x4*>(st.relu + (int64_t)l * st.Mpad * 8) + tix * 64 + lane;
+  };
   ActRegs<WT> act, nxt;
   {
     ActRegs<2> enc;
@@ -203,12 +214,12 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
       store_frag(e, 0, 0, enc.v[0][0][0]); store_frag(e, 0, 1, enc.v[0][0][1]);
       store_frag(e, 1, 0, enc.v[0][1][0]); store_frag(e, 1, 1, enc.v[0][1][1]);
     }
-    EpiTrunk<WT, TRAIN> epi{act, TRAIN ? tile_lane(st.act, WT) : nullptr};
+    EpiTrunk<WT, TRAIN> epi{act, TRAIN ? tile_lane(st.act, WT) : nullptr, TRAIN ? bits_lane(0) : nullptr, rg, {0u, 0u, 0u, 0u}};
     run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
   }
   // layers 1..D-1, two per trip (act -> nxt -> act) so the activations never have to be copied
   auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) {
-    EpiTrunk<WT, TRAIN> epi{out, TRAIN ? tile_lane(st.act + (int64_t)l * R * st.Mpad, WT) : nullptr};
+    EpiTrunk<WT, TRAIN> epi{out, TRAIN ? tile_lane(st.act + (int64_t)l * R * st.Mpad, WT) : nullptr, TRAIN ? bits_lane(l) : nullptr, rg, {0u, 0u, 0u, 0u}};
     const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
     if ((net.skip_mask >> (l - 1)) & 1u) {
       // recompute the encoding HERE: made opaque so that it is not hoisted out of the layer loop (it would then be
