@@ -147,6 +147,7 @@ def main():
                 "ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kern.items()},
                 "tflops": {k: round(v[1] / max(v[0], 1e-9) / 1e9, 2) for k, v in kern.items()},
                 "other_ms_per_step": round((prof["composite_ms"] + prof["sampling_ms"] + prof["other_ms"]) / args.steps, 4)}
+    roofline.update(pmc_traffic(dom, args.dtype))
     r_ach = rprof["mlp_fwd_flop"] / max(rprof["mlp_fwd_ms"], 1e-9) / 1e9
     render = {"metric": "rays/sec (render)", "value": round(render_rays_s, 1), "unit": "rays/s",
               "workload": f"{HW}x{HW} frame, {n_frame} rays/GPU/frame", "frames": args.render_frames,
@@ -286,6 +287,27 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(dom, dtype):
+    """HBM bytes per train step of the dominant kernel from the committed rocprofv3 PMC passes of this workload
+    (scripts/pmc_train.sh: separate FETCH_SIZE and WRITE_SIZE passes over 3 steps of the same 4096-ray batch;
+    units KB; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect
+    counters itself, so this is read from profiles/; null when the summaries are absent."""
+    import csv
+    sub = {"mlp_wgrad": "wgrad_%s_kernel", "mlp_fwd": "mlp_fwd_%s_kernel<8, 1, true>" if dtype == "bf16" else "mlp_fwd_%s_kernel<8, true>",
+           "mlp_bwd": "mlp_bwd_%s_kernel"}[dom] % dtype
+    tot = 0.0
+    try:
+        for kind, col, mul in (("fetchsize", "FETCH_SIZE", 2.0), ("writesize", "WRITE_SIZE", 1.0)):
+            path = os.path.join(ROOT, "profiles", f"r1_final_{dtype}_pmc_{kind}.csv")
+            for r in csv.DictReader(open(path)):
+                if sub in r["kernel"]:
+                    tot += mul * float(r[col]) * 1024.0 / 3.0     # 3 profiled steps
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+    return {"traffic": round(tot), "traffic_unit": "bytes per train step (all launches of the kernel)",
+            "traffic_source": f"profiles/r1_final_{dtype}_pmc_fetchsize.csv, _writesize.csv"}
 
 
 def cpu_baseline(base, t_o, t_d, t_b, t_l, seconds):

@@ -494,6 +494,11 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
     return bad("NImportance must be >= 1 and NSamples+NImportance <= 2048");
   if (c.max_rays < 1) return bad("max_rays must be >= 1");
   if (c.dtype != NERFHIP_F32 && c.dtype != NERFHIP_BF16) return bad("unknown dtype");
+  if (c.dtype == NERFHIP_BF16) {   // limits of the bf16 kernels (tile indices are 32-bit; W/32 in {2,4,8})
+    if (c.W == 32) return bad("dtype bf16 needs W = 64, 128 or 256");
+    const long long smax = c.use_hierarchical ? c.n_samples + c.n_importance : c.n_samples;
+    if ((long long)c.max_rays * smax >= (1LL << 31)) return bad("dtype bf16: max_rays x samples per ray must be < 2^31");
+  }
   if (c.lrate_decay <= 0) return bad("lrateDecay must be > 0");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
