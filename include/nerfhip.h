@@ -94,7 +94,11 @@ typedef struct nerfhip_aux {
 int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out);
 void nerfhip_destroy(nerfhip_t* h);
 const char* nerfhip_last_error(const nerfhip_t* h);   /* h may be NULL: last create() error */
-/* Run on a caller-owned HIP stream (hipStream_t as void*); NULL = the library's own stream. */
+/* Run on a caller-owned HIP stream (hipStream_t as void*); NULL = the library's own NON-BLOCKING stream (the
+ * legacy default stream cannot be selected: it is the NULL handle).  The _dev entry points and
+ * nerfhip_optimizer_step are asynchronous: a caller that interleaves them with its own GPU work or with
+ * collectives on the gradient buffer must either share one explicit stream with the library or call
+ * nerfhip_synchronize in between. */
 int nerfhip_set_stream(nerfhip_t* h, void* hip_stream);
 int nerfhip_synchronize(nerfhip_t* h);
 

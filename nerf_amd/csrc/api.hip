@@ -312,10 +312,11 @@ int repack(nerfhip* h) {
   for (int i = 0; i < h->nnets; ++i) {
     Net& n = h->nets[i];
     const float* p = h->d_params + n.param_off;
-    HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));
-    HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
-    HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
-    if (h->cfg.dtype == NERFHIP_BF16) {
+    if (h->cfg.dtype != NERFHIP_BF16) {   // the fp32 kernels' tile images
+      HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));
+      HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
+      HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
+    } else {
       HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_full_desc, (int)n.bf_full.size(), n.d_bf_full, h->stream));
       HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_sigma_desc, (int)n.bf_sigma.size(), n.d_bf_sigma, h->stream));
       HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_bwd_desc, (int)n.bf_bwd.size(), n.d_bf_bwd, h->stream));

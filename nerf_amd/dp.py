@@ -31,6 +31,20 @@ def grad_tensor(block):
     return torch.as_tensor(_CudaView(ptr, n), device=f"cuda:{block.config.device}")
 
 
+def shared_stream(*blocks, device=None):
+    """Create a torch stream, make it current and hand it to every block.
+
+    The device-pointer entry points (`train_backward_dev`, `optimizer_step`, `render_dev`) are asynchronous, so the
+    gradient all-reduce must be ordered against them ON A STREAM: torch's collectives are ordered after the
+    current torch stream and make it wait for their result.  The library cannot run on the legacy default stream
+    (`set_stream(0)` selects its own non-blocking stream), hence an explicit one.  Returns the torch stream."""
+    s = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(s)
+    for b in blocks:
+        b.set_stream(s.cuda_stream)
+    return s
+
+
 def row_block(H, rank, world):
     """rows [r0, r1) of an H-row image rendered by `rank`: contiguous, sizes differ by at most one row."""
     base, rem = divmod(H, world)

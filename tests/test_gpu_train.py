@@ -206,3 +206,38 @@ def test_dp_path_world1_nccl(G):
         a.close(); b.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_dp_async_path_on_shared_stream(G):
+    """bench.py's data-parallel loop: asynchronous train_backward_dev -> all_reduce -> optimizer_step, ordered on
+    one explicit stream shared by the library, torch and RCCL (nerf_amd.dp.shared_stream); equals train_step."""
+    import torch
+    import torch.distributed as dist
+    from nerf_amd.dp import grad_tensor, shared_stream
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29613")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    prev = torch.cuda.current_stream()
+    try:
+        c = H.CONFIGS["small_dir"]
+        g = load("small_dir_train")
+        params = H.make_params(c, 1)
+        a, b = G.make_block(c), G.make_block(c)
+        for blk in (a, b):
+            blk.set_params(params)
+        s = shared_stream(a)
+        assert s.cuda_stream != 0
+        dev = [G.dev(g[k]) for k in ("rays_o", "rays_d", "bounds", "rays_d", "label")]
+        n = g["rays_o"].shape[0]
+        gt = grad_tensor(a)
+        for _ in range(3):
+            a.train_backward_dev(*dev, n)
+            dist.all_reduce(gt)
+            a.optimizer_step(1.0)
+            b.train_step(g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"])
+        s.synchronize()
+        np.testing.assert_allclose(a.get_params(), b.get_params(), rtol=0, atol=1e-6)
+        a.close(); b.close()
+    finally:
+        torch.cuda.set_stream(prev)
+        dist.destroy_process_group()
