@@ -27,19 +27,8 @@ constexpr int kWgChunkFloats = kWgRows * 32; // one operand, one chunk: 256 rows
 constexpr int kWgBufBytes = 2 * kWgChunkFloats * 4;   // one buffer = A chunk | B chunk = 64 KiB
 
 // LDS image of one operand chunk: [row][8 x 16-byte slots], slot s of row r holds samples
-// 4*(s ^ swz(r)) .. +3 with swz(r) = (r >> 1) & 7  (conflict-free ds_read_b128 across 16 rows)
-__device__ __forceinline__ void stage_operand(const float* g, int rows, float* lds, int wave, int lane) {
-  // wave-instruction u covers rows 8u..8u+7 (64 lanes x 16 B = 8 rows x 128 B)
-  const int nrow8 = (rows + 7) >> 3;
-  for (int u = wave; u < nrow8; u += 4) {
-    int r = 8 * u + (lane >> 3);
-    const int s = lane & 7;
-    const int rs = r < rows ? r : rows - 1;  // clamp: rows past the end duplicate the last row (never stored)
-    const int src_slot = s ^ ((r >> 1) & 7);
-    __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(g + rs * 32 + 4 * src_slot),
-                                     NERFHIP_LPTR(lds + u * 256), 16, 0, 0);
-  }
-}
+// 4*(s ^ swz(r)) .. +3 with swz(r) = (r >> 1) & 7  (conflict-free ds_read_b128 across 16 rows); staged by LDS-DMA
+// with the swizzle applied on the source side (wgrad_body: offA / offB).
 
 // Fragment reads are inline asm with counted lgkmcnt waits (the compiler would otherwise put every
 // ds_read_b128 right in front of its MFMAs behind an lgkmcnt(0)): the AT+BT reads of k-group g+1 are issued
@@ -99,12 +88,34 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
 #pragma unroll
   for (int g = 0; g < 4; ++g) xoff[g] = 16u * ((uint32_t)(2 * g + h) ^ sw);
 
+  // Staging: wave-instruction u of an operand covers rows 8u..8u+7 (64 lanes x 16 B); this wave issues u = wave + 4t,
+  // t < 8.  The per-lane source offsets (row clamp + swizzle) are computed once; per chunk only the scalar base
+  // moves.  The pieces of a chunk are NOT issued in one burst (an LDS-DMA instruction costs 60-185 issue cycles
+  // next to LDS reads): part 0 goes behind the hand-over barrier, parts 1 and 2 into the next chunk's first two
+  // k-groups, each among that group's MFMAs; all of them have landed at the next hand-over (vmcnt(0)).
   const int64_t a_step = (int64_t)it.a_stride * 32, b_step = (int64_t)it.b_stride * 32;   // floats per chunk
-  auto stage = [&](int c, int buf) {
+  const int nA8 = (it.a_rows + 7) >> 3, nB8 = (it.b_rows + 7) >> 3;
+  uint32_t offA[8], offB[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = 8 * (wave + 4 * t) + (lane >> 3), sl = (lane & 7) ^ ((r >> 1) & 7);
+    offA[t] = (uint32_t)((min(r, it.a_rows - 1) * 32 + 4 * sl) * 4);   // rows past the end repeat the last row (never stored)
+    offB[t] = (uint32_t)((min(r, it.b_rows - 1) * 32 + 4 * sl) * 4);
+  }
+  auto stage_part = [&](int c, int buf, int part) {   // part 0: t = 0,1; part 1: t = 2..4; part 2: t = 5..7
     float* dst = smem + buf * 2 * kWgChunkFloats;
-    stage_operand(it.A + c * a_step, it.a_rows, dst, wave, lane);
-    stage_operand(it.B + c * b_step, it.b_rows, dst + kWgChunkFloats, wave, lane);
+    const char* ga = reinterpret_cast<const char*>(it.A + c * a_step);
+    const char* gb = reinterpret_cast<const char*>(it.B + c * b_step);
+    const int t0 = part == 0 ? 0 : (part == 1 ? 2 : 5), t1 = part == 0 ? 2 : (part == 1 ? 5 : 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t < t0 || t >= t1) continue;
+      const int u = wave + 4 * t;
+      if (u < nA8) __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(ga + offA[t]), NERFHIP_LPTR(dst + u * 256), 16, 0, 0);
+      if (u < nB8) __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(gb + offB[t]), NERFHIP_LPTR(dst + kWgChunkFloats + u * 256), 16, 0, 0);
+    }
   };
+  auto stage = [&](int c, int buf) { stage_part(c, buf, 0); stage_part(c, buf, 1); stage_part(c, buf, 2); };
   stage(c0, 0);
   if (c0 + 1 < c1) stage(c0 + 1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -131,10 +142,14 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
   // request of the chunk after it, first fragment reads) sits between the last wait and the last MFMAs.
   auto chunk = [&](int c, bool has_next) {
     const uint32_t cur = (uint32_t)((c - c0) & 1) * (uint32_t)kWgBufBytes;
+    // chunk c+1's remaining pieces go into the buffer chunk c-1 used (free since the last hand-over)
+    const bool more = c > c0 && c + 1 < c1;
     reads(1, cur, 1);
+    if (more) stage_part(c + 1, (c + 1 - c0) & 1, 1);
     wait_lgkm<AT + BT>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]);
     mfmas(fa[0], fb[0]);
     reads(0, cur, 2);
+    if (more) stage_part(c + 1, (c + 1 - c0) & 1, 2);
     wait_lgkm<AT + BT>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]);
     mfmas(fa[1], fb[1]);
     reads(1, cur, 3);
@@ -142,10 +157,10 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
     mfmas(fa[0], fb[0]);
     wait_lgkm<0>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]);
     if (has_next) {
-      // every wave is done READING this buffer; chunk c+1 (requested one chunk ago) must have landed for all
+      // every wave is done READING this buffer; chunk c+1 must have landed for all
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (c + 2 < c1) stage(c + 2, (c - c0) & 1);
+      if (c + 2 < c1) stage_part(c + 2, (c - c0) & 1, 0);
       reads(0, cur ^ (uint32_t)kWgBufBytes, 0);
     }
     mfmas(fa[1], fb[1]);   // ... all of it behind these MFMAs
