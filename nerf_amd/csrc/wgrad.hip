@@ -17,6 +17,7 @@
 // The k order inside an 8-sample group is permuted (lane half h takes samples 4h..4h+3) identically for A
 // and B, so one 16-byte LDS read feeds four MFMAs.
 #include "mlp_common.cuh"
+#include <type_traits>
 #include "launchers.h"
 
 namespace nh {
@@ -102,20 +103,25 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
     offA[t] = (uint32_t)((min(r, it.a_rows - 1) * 32 + 4 * sl) * 4);   // rows past the end repeat the last row (never stored)
     offB[t] = (uint32_t)((min(r, it.b_rows - 1) * 32 + 4 * sl) * 4);
   }
-  auto stage_part = [&](int c, int buf, int part) {   // part 0: t = 0,1; part 1: t = 2..4; part 2: t = 5..7
+  // 256x256-class products (AT = BT = 4, 7 of every 8.5 chunks): the pieces are issued BETWEEN the k-steps of the
+  // MFMAs, branch-free (a branch inside the MFMA region makes the compiler copy registers that asm reads still
+  // have in flight); other shapes issue theirs in front of the k-group's MFMAs.
+  constexpr bool SPREAD = AT == 4 && BT == 4;
+  auto stage_t = [&](int c, int buf, int t) {   // pieces u = wave + 4t of both operands of chunk c
     float* dst = smem + buf * 2 * kWgChunkFloats;
     const char* ga = reinterpret_cast<const char*>(it.A + c * a_step);
     const char* gb = reinterpret_cast<const char*>(it.B + c * b_step);
-    const int t0 = part == 0 ? 0 : (part == 1 ? 2 : 5), t1 = part == 0 ? 2 : (part == 1 ? 5 : 8);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (t < t0 || t >= t1) continue;
-      const int u = wave + 4 * t;
-      if (u < nA8) __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(ga + offA[t]), NERFHIP_LPTR(dst + u * 256), 16, 0, 0);
-      if (u < nB8) __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(gb + offB[t]), NERFHIP_LPTR(dst + kWgChunkFloats + u * 256), 16, 0, 0);
-    }
+    const int u = wave + 4 * t;
+    const uint32_t oa = t == 0 ? offA[0] : t == 1 ? offA[1] : t == 2 ? offA[2] : t == 3 ? offA[3] : t == 4 ? offA[4] : t == 5 ? offA[5] : t == 6 ? offA[6] : offA[7];
+    const uint32_t ob = t == 0 ? offB[0] : t == 1 ? offB[1] : t == 2 ? offB[2] : t == 3 ? offB[3] : t == 4 ? offB[4] : t == 5 ? offB[5] : t == 6 ? offB[6] : offB[7];
+    // SPREAD: no conditions (a piece past the operand's rows re-reads its last row into an image row nobody stores)
+    if (SPREAD || u < nA8) __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(ga + oa), NERFHIP_LPTR(dst + u * 256), 16, 0, 0);
+    if (SPREAD || u < nB8) __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(gb + ob), NERFHIP_LPTR(dst + kWgChunkFloats + u * 256), 16, 0, 0);
   };
-  auto stage = [&](int c, int buf) { stage_part(c, buf, 0); stage_part(c, buf, 1); stage_part(c, buf, 2); };
+  auto stage = [&](int c, int buf) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) stage_t(c, buf, t);
+  };
   stage(c0, 0);
   if (c0 + 1 < c1) stage(c0 + 1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -126,44 +132,81 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
     if (set == 0) { read_frags<AT>(fa[0], laneA + bufoff + xoff[g]); read_frags<BT>(fb[0], laneB + bufoff + xoff[g]); }
     else          { read_frags<AT>(fa[1], laneA + bufoff + xoff[g]); read_frags<BT>(fb[1], laneB + bufoff + xoff[g]); }
   };
-  auto mfmas = [&](f32x4 (&a)[AT], f32x4 (&b)[BT]) {
+  // the 4 x AT x BT MFMAs of one k-group; SPREAD and PART >= 0: the staging pieces of part PART of chunk pc are
+  // issued between the k-steps (part 0: t = 0,1; part 1: t = 2,3,4; part 2: t = 5,6,7)
+  auto mfmas = [&](f32x4 (&a)[AT], f32x4 (&b)[BT], auto part, int pc, int pbuf) {
+    constexpr int PART = decltype(part)::value;
     if (do_bias) {
 #pragma unroll
       for (int i = 0; i < AT; ++i) bs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k) {
 #pragma unroll
       for (int i = 0; i < AT; ++i)
 #pragma unroll
         for (int j = 0; j < BT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
+      if constexpr (SPREAD) {   // pc is always a chunk of this entry (see chunk()): no condition needed
+        if constexpr (PART == 0) { if (k == 0 || k == 2) stage_t(pc, pbuf, k / 2); }
+        if constexpr (PART == 1) { if (k < 3) stage_t(pc, pbuf, 2 + k); }
+        if constexpr (PART == 2) { if (k < 3) stage_t(pc, pbuf, 5 + k); }
+      }
+    }
+    if constexpr (SPREAD && PART >= 0) {   // keep the scheduler from bunching the pieces: one per 8 MFMAs
+      constexpr int NP = PART == 0 ? 4 : 6;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // VMEM (LDS-DMA)
+      }
+    }
   };
+  auto burst = [&](auto part, bool go, int pc, int pbuf) {   // the same pieces, in front of the k-group (!SPREAD)
+    constexpr int PART = decltype(part)::value;
+    if constexpr (!SPREAD) {
+      if (go) {
+        if constexpr (PART == 0) { stage_t(pc, pbuf, 0); stage_t(pc, pbuf, 1); }
+        if constexpr (PART == 1) { stage_t(pc, pbuf, 2); stage_t(pc, pbuf, 3); stage_t(pc, pbuf, 4); }
+        if constexpr (PART == 2) { stage_t(pc, pbuf, 5); stage_t(pc, pbuf, 6); stage_t(pc, pbuf, 7); }
+      }
+    }
+  };
+  using P_ = std::integral_constant<int, -1>;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
   // One chunk: k-groups 0..3.  With a chunk to follow, the hand-over to its buffer (DMA landed for everyone,
-  // request of the chunk after it, first fragment reads) sits between the last wait and the last MFMAs.
+  // first fragment reads) sits between the last wait and the last MFMAs.
   auto chunk = [&](int c, bool has_next) {
     const uint32_t cur = (uint32_t)((c - c0) & 1) * (uint32_t)kWgBufBytes;
-    // chunk c+1's remaining pieces go into the buffer chunk c-1 used (free since the last hand-over)
+    // Chunk c+1's parts 1 and 2 go into the buffer chunk c-1 used (free since the last hand-over).  SPREAD issues
+    // unconditionally: in the first chunk that re-stages chunk c0+1 (identical bytes over a buffer nobody reads
+    // yet), past the end it stages the last chunk into the buffer nobody reads any more.
     const bool more = c > c0 && c + 1 < c1;
+    const int nbuf = (c + 1 - c0) & 1;
+    const int pc1 = min(c + 1, c1 - 1), pc2 = min(c + 2, c1 - 1);
     reads(1, cur, 1);
-    if (more) stage_part(c + 1, (c + 1 - c0) & 1, 1);
+    burst(P1{}, more, c + 1, nbuf);
     wait_lgkm<AT + BT>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]);
-    mfmas(fa[0], fb[0]);
+    mfmas(fa[0], fb[0], P1{}, pc1, nbuf);
     reads(0, cur, 2);
-    if (more) stage_part(c + 1, (c + 1 - c0) & 1, 2);
+    burst(P2{}, more, c + 1, nbuf);
     wait_lgkm<AT + BT>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]);
-    mfmas(fa[1], fb[1]);
+    mfmas(fa[1], fb[1], P2{}, pc1, nbuf);
     reads(1, cur, 3);
     wait_lgkm<AT + BT>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]);
-    mfmas(fa[0], fb[0]);
+    mfmas(fa[0], fb[0], P_{}, 0, 0);
     wait_lgkm<0>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]);
     if (has_next) {
       // every wave is done READING this buffer; chunk c+1 must have landed for all
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (c + 2 < c1) stage_part(c + 2, (c - c0) & 1, 0);
+      burst(P0{}, c + 2 < c1, c + 2, (c - c0) & 1);
       reads(0, cur ^ (uint32_t)kWgBufBytes, 0);
+      mfmas(fa[1], fb[1], P0{}, pc2, (c - c0) & 1);   // ... all of it behind these MFMAs
+    } else {
+      mfmas(fa[1], fb[1], P_{}, 0, 0);
     }
-    mfmas(fa[1], fb[1]);   // ... all of it behind these MFMAs
   };
   reads(0, 0u, 0);
   for (int c = c0; c < c1 - 1; ++c) chunk(c, true);
