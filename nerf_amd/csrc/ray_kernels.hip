@@ -240,20 +240,31 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 // hierarchical inverse-CDF resampling: one wave per ray, CDF and bins staged in LDS
 // dynamic LDS per wave: cdf[Npad] + bins[Npad] + sortbuf[P] + ubuf[PU]
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bitonic_sort_lds(float* a, int P, int lane) {
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = lane; i < P; i += 64) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const float x = a[i], y = a[ixj];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) { a[i] = y; a[ixj] = x; }
-        }
-      }
-      __syncthreads();
+// every wave sorts its own ray's buffer: LDS operations of one wave execute in order, so a wave-level fence is all
+// the synchronisation a compare-exchange stage needs (no s_barrier: waves may take different paths below)
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void bitonic_stage(float* a, int P, int lane, int k, int j) {
+  for (int i = lane; i < P; i += 64) {
+    const int ixj = i ^ j;
+    if (ixj > i) {
+      const float x = a[i], y = a[ixj];
+      const bool up = (i & k) == 0;
+      if ((x > y) == up) { a[i] = y; a[ixj] = x; }
     }
   }
+  wave_sync_lds();
+}
+__device__ __forceinline__ void bitonic_sort_lds(float* a, int P, int lane) {
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) bitonic_stage(a, P, lane, k, j);
+}
+// a[0..P) is bitonic (ascending, then descending): log2(P) stages instead of log2(P)(log2(P)+1)/2
+__device__ __forceinline__ void bitonic_merge_lds(float* a, int P, int lane) {
+  for (int j = P >> 1; j > 0; j >>= 1) bitonic_stage(a, P, lane, P, j);
 }
 
 __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ w, const float* __restrict__ z,
@@ -317,9 +328,26 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
       if (zs_out) zs_out[ray * NI + m] = s;
     }
   }
-  for (int i = lane; i < P - NI; i += 64) sb[NI + i] = (i < N) ? zr[i] : __builtin_inff();
-  __syncthreads();
-  bitonic_sort_lds(sb, P, lane);  // sort(concat(samples, z))  (nerfBlock.scala:101)
+  // sort(concat(samples, z)) (nerfBlock.scala:101).  The samples are non-decreasing in m (u is sorted and every step
+  // of the inverse CDF is monotone under round-to-nearest) and z normally ascends, so the concatenation
+  // [samples | +inf padding | z reversed] is bitonic and ONE merge sorts it -- the same multiset in the same order
+  // as a full sort.  A ray whose z (caller-supplied through the debug entry point) or samples do not ascend takes
+  // the full sort.
+  wave_sync_lds();
+  bool ordered = true;
+  for (int m = lane; m + 1 < NI; m += 64) ordered = ordered && (sb[m] <= sb[m + 1]);
+  for (int i = lane; i + 1 < N; i += 64) ordered = ordered && (zr[i] <= zr[i + 1]);
+  ordered = __all(ordered);
+  wave_sync_lds();
+  if (ordered) {
+    for (int i = lane; i < P - NI; i += 64) { const int r = P - NI - 1 - i; sb[NI + i] = (r < N) ? zr[r] : __builtin_inff(); }
+    wave_sync_lds();
+    bitonic_merge_lds(sb, P, lane);
+  } else {
+    for (int i = lane; i < P - NI; i += 64) sb[NI + i] = (i < N) ? zr[i] : __builtin_inff();
+    wave_sync_lds();
+    bitonic_sort_lds(sb, P, lane);
+  }
   if (live)
     for (int i = lane; i < N + NI; i += 64) z_fine[ray * (N + NI) + i] = sb[i];
 }

@@ -70,6 +70,33 @@ def test_sample_pdf_bit_exact(G, name, N, NI):
     blk.close()
 
 
+def test_sample_pdf_unsorted_depths(G):
+    """The reference sorts concat(samples, z) whatever z is (nerfBlock.scala:101).  The kernel merges when z ascends
+    and falls back to a full sort per ray otherwise: rays with shuffled / descending / constant z, mixed with
+    ordinary ones in the same workgroup, still match the oracle bit for bit."""
+    import torch
+    c = H.cfg(**{**H.CONFIGS["full"], "NSamples": 64, "NImportance": 128})
+    n, N, NI = 203, 64, 128
+    o = Oracle(c)
+    _, _, bounds, _ = H.make_rays(n, 6)
+    z = o.stratified(bounds).copy()
+    rng = np.random.default_rng(3)
+    for r in range(0, n, 3):
+        z[r] = z[r][rng.permutation(N)]          # shuffled
+    z[1] = z[1][::-1]                             # descending
+    z[4] = z[4][0]                                # constant
+    w = (H.det_uniform(n * N, 11).reshape(n, N) ** 2).astype(np.float32)
+    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    blk = G.make_block(c)
+    ind, zf = G.empty(n, NI, dtype=torch.int32), G.empty(n, N + NI)
+    blk.k_sample_pdf(G.dev(w), G.dev(z), None, n, None, ind, None, zf)
+    blk.synchronize()
+    _, ri, _, rf = o.sample_pdf(w, z, None)
+    np.testing.assert_array_equal(ind.cpu().numpy(), ri)
+    np.testing.assert_array_equal(zf.cpu().numpy(), rf)
+    blk.close()
+
+
 def test_sample_pdf_golden(G):
     import torch
     for case in ("full_eval", "small_opts_eval"):
