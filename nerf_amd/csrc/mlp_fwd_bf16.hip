@@ -65,13 +65,9 @@ struct EpiTrunk {   // relu + bf16 -> B operand of the next layer (TRAIN: also i
     static_assert(kNS == 1, "store addressing assumes one sample tile per wave");
     out.v[P / 2][OT_IDX][P % 2] = relu_pack_half<P % 2>(acc[P / 2]);
     if constexpr (TRAIN) {
-#ifndef NERFHIP_EXP_NOSTORE
       store_frag(dst, OT_IDX, P % 2, out.v[P / 2][OT_IDX][P % 2]);
       rg.note(1);
-#endif
-#ifndef NERFHIP_EXP_NOBITS
       relu_bits_gather<OT_IDX, P % 2>(bits, out.v[P / 2][OT_IDX][P % 2]);
-#endif
       if constexpr (OT_IDX == WT - 1 && P == kPieces - 1) { *bits_dst = bits; rg.note(1); }
     }
   }
