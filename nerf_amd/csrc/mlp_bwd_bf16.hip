@@ -38,7 +38,9 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile_lane, int kt, int s
   return *reinterpret_cast<const bf16x8*>(tile_lane + (kt * 2 + s) * 1024);
 }
 __device__ __forceinline__ void store_frag_b(char* tile_lane, int kt, int s, const bf16x8& v) {
-  *reinterpret_cast<bf16x8*>(tile_lane + (kt * 2 + s) * 1024) = v;
+  // streaming data (read once, much later, by another kernel): non-temporal, so that it does not push the weight
+  // streams out of the XCD's L2
+  __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(tile_lane + (kt * 2 + s) * 1024));
 }
 
 template <int WT>

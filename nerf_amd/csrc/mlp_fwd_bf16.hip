@@ -51,7 +51,9 @@ __device__ __forceinline__ void encode_half(ActRegs<2>& enc, const float (&pos)[
 
 // one 16-byte store per lane: fragment (kt, s) of this wave's sample tile (BfStore layout, common.h)
 __device__ __forceinline__ void store_frag(char* tile_lane, int kt, int s, const bf16x8& v) {
-  *reinterpret_cast<bf16x8*>(tile_lane + (kt * 2 + s) * 1024) = v;
+  // streaming data (read once, much later, by another kernel): non-temporal, so that it does not push the weight
+  // streams out of the XCD's L2
+  __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(tile_lane + (kt * 2 + s) * 1024));
 }
 template <int WT, bool TRAIN>
 struct EpiTrunk {   // relu + bf16 -> B operand of the next layer (TRAIN: also into the activation store)
