@@ -102,7 +102,9 @@ __device__ __forceinline__ void gload4u(uint32_t& d, const uint32_t* sbase, uint
 template <int OFF>   // immediate byte offset, < 4096
 __device__ __forceinline__ void gstore4(float* sbase, uint32_t voff, float v) {
   static_assert(OFF >= 0 && OFF < 4096, "global immediate offset");
-  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase), "n"(OFF));
+  // nt: the stored activations / gradients are read once, much later, by another kernel; non-temporal keeps them from
+  // pushing the packed weight stream (which every wave re-reads from L2) out of the XCD's L2
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(sbase), "n"(OFF));
 }
 constexpr int kNB = 4;   // fragment ring: 1 computing + 3 tiles (768 MFMA-cycles) in flight
 
