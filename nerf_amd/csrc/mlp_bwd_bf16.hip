@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_bwd_bf16_kernel(NetArgs net
     return reinterpret_cast<const u32x4*>(st.relu + (int64_t)l * st.Mpad * 8) + tix_ * 64 + lane;
   };
   u32x4 bitsA = {0u, 0u, 0u, 0u}, bitsB = bitsA, bitsN = bitsA;
-  if ((int)blockIdx.x < ntiles) bitsA = *bits_lane(D - 1, (int64_t)blockIdx.x * kBfWaves + wave);
+  if ((int)blockIdx.x < ntiles) bitsA = __builtin_nontemporal_load(bits_lane(D - 1, (int64_t)blockIdx.x * kBfWaves + wave));
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m = tile * kBfTile + wave * 32 + li;
     const bool valid = m < (int)M;
@@ -193,15 +193,15 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_bwd_bf16_kernel(NetArgs net
     const int64_t tnext = (int64_t)(tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile) * kBfWaves + wave;
     GradRegs<WT> g, gn;
     {
-      if (D >= 2) { bitsB = *bits_lane(D - 2, tix); rg.note(1); }
-      else { bitsN = *bits_lane(D - 1, tnext); rg.note(1); }
+      if (D >= 2) { bitsB = __builtin_nontemporal_load(bits_lane(D - 2, tix)); rg.note(1); }
+      else { bitsN = __builtin_nontemporal_load(bits_lane(D - 1, tnext)); rg.note(1); }
       EpiGradBits<WT> epi{g, tile_lane(st.dy + (int64_t)(D - 1) * R * st.Mpad, WT), rg, bitsA};
       run_part<2 * HT + 1, WT, false>(rg, 0u, SelHead<HT>{dh, dsig}, epi);
     }
     // ---- trunk, last layer first: dY_{l-1} = ReLU'_{l-1} . (W_l^T . dY_l); two layers per trip (g -> gn -> g)
     auto layer = [&](int l, const GradRegs<WT>& in, GradRegs<WT>& out, const u32x4& use, u32x4& fetch) {
-      if (l >= 2) fetch = *bits_lane(l - 2, tix);
-      else bitsN = *bits_lane(D - 1, tnext);
+      if (l >= 2) fetch = __builtin_nontemporal_load(bits_lane(l - 2, tix));
+      else bitsN = __builtin_nontemporal_load(bits_lane(D - 1, tnext));
       rg.note(1);
       EpiGradBits<WT> epi{out, tile_lane(st.dy + (int64_t)(l - 1) * R * st.Mpad, WT), rg, use};
       run_part<2 * WT, WT, false>(rg, 0u, SelGrad<WT>{in}, epi);

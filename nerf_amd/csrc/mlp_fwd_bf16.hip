@@ -70,7 +70,7 @@ struct EpiTrunk {   // relu + bf16 -> B operand of the next layer (TRAIN: also i
       store_frag(dst, OT_IDX, P % 2, out.v[P / 2][OT_IDX][P % 2]);
       rg.note(1);
       relu_bits_gather<OT_IDX, P % 2>(bits, out.v[P / 2][OT_IDX][P % 2]);
-      if constexpr (OT_IDX == WT - 1 && P == kPieces - 1) { *bits_dst = bits; rg.note(1); }
+      if constexpr (OT_IDX == WT - 1 && P == kPieces - 1) { __builtin_nontemporal_store(bits, bits_dst); rg.note(1); }
     }
   }
 };
