@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--no-bf16-render", action="store_true")
     ap.add_argument("--no-bf16-train", action="store_true", help="skip the bf16 training legs (same batch; config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dp", action="store_true", help="take the data-parallel code path (backward, all-reduce, "
+                    "optimizer step) even with one rank: rehearsal of the N > 1 loop on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -52,8 +54,25 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dp = world > 1 or args.force_dp
+    if dp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout carries exactly one JSON line,
+        # so file descriptor 1 points at stderr until the communicator exists (eager init + one tiny all-reduce)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     # one explicit stream for the library's kernels, torch's tensor ops and (through torch) the RCCL collectives:
     # the all-reduce is ordered after the backward kernels and the Adam kernel after the all-reduce on it
     tstream = torch.cuda.Stream(device=local)
@@ -90,10 +109,10 @@ def main():
     gsel = torch.Generator(device="cpu").manual_seed(100 + rank)
     idx = torch.randperm(n_frame, generator=gsel)[:B].cuda()
     t_o, t_d, t_b, t_l = ro[idx].contiguous(), rd[idx].contiguous(), bd[idx].contiguous(), label_full[idx].contiguous()
-    grad = grad_tensor(trainer) if world > 1 else None   # zero-copy torch view of the flat gradient buffer
+    grad = grad_tensor(trainer) if dp else None   # zero-copy torch view of the flat gradient buffer
 
     def train_step():
-        if world == 1:
+        if not dp:
             trainer.train_step_dev(t_o, t_d, t_b, t_d, t_l, B)
         else:
             trainer.train_backward_dev(t_o, t_d, t_b, t_d, t_l, B)
@@ -101,7 +120,7 @@ def main():
             trainer.optimizer_step(1.0 / world)                    # mean over devices
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -192,10 +211,10 @@ def main():
     # ---- bf16-MFMA training legs: the same batch (configs[3] arithmetic in bf16), and BASELINE configs[4]:
     # 1024x1024 forward-facing scene, NDC rays (llff.scala:96-132), 64 + 256 samples per ray
     def timed_train(blk, o_, d_, b_, l_, nsteps):
-        g = grad_tensor(blk) if world > 1 else None
+        g = grad_tensor(blk) if dp else None
 
         def one():
-            if world == 1:
+            if not dp:
                 blk.train_step_dev(o_, d_, b_, d_, l_, B)
             else:
                 blk.train_backward_dev(o_, d_, b_, d_, l_, B)
@@ -324,7 +343,7 @@ def main():
                 "roofline": roofline, "render": render, "render_bf16": render_bf16, "train_bf16": train_bf16,
                 "config5_bf16": config5, "hbm_kernels": hbm_kernels, "cpu_baseline": cpu}
         print(json.dumps(line))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 
