@@ -26,20 +26,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char lds_char;
 
-__device__ __forceinline__ void wait_vm_dyn(int n) {   // s_waitcnt vmcnt(n), n wave-uniform (smaller = stricter)
-  if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // LDS image of one staged fragment (64 lanes x 16 B, lane = 32*hp + sample): the 16-byte slot of (hp, sample m) is
 //   32*hp + (m & 16) + ((m + 8*s + 4*hp) & 15),   s = the fragment's k-step
 // so that the 32 eight-byte pieces one half-wave fetches in a transposed read (2 k-steps x 2 lane halves x 4
