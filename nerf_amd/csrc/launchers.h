@@ -59,6 +59,9 @@ struct WgradBfItem {
   int64_t a_stride, b_stride;   // bytes per 32-sample tile of the buffers A and B live in
   int32_t a_rows, b_rows;       // rows (features) of the operands, counted from their first k-tile
   int32_t a_row0;               // rows of A below a_row0 are not part of the product (dW row = row - a_row0)
+  int32_t split;                // rows >= split go to dW2 / db2 (row - split) instead: two weight tensors fed by one
+  float* dW2;                   // pass over the operands (head matrix + density row); split >= a_rows: unused
+  float* db2;
   int32_t ldo, col0;
   int32_t c0, c1;               // slice of the sample axis in 32-sample tiles
   int32_t wb_n, shape;          // as WgradItem

@@ -189,16 +189,18 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * (a_tile0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= it.a_row0 && row < it.a_rows && col < it.b_rows)
-          __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(it.dW + (int64_t)(row - it.a_row0) * it.ldo + it.col0 + col),
-                                 acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (row >= it.a_row0 && row < it.a_rows && col < it.b_rows) {
+          float* o = row < it.split ? it.dW + (int64_t)(row - it.a_row0) * it.ldo : it.dW2 + (int64_t)(row - it.split) * it.ldo;
+          __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(o + it.col0 + col), acc[i][j][r], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     if (do_bias[i]) {   // both lane halves hold a partial sum of row li
       const int row = 32 * (a_tile0 + i) + li;
       if (row >= it.a_row0 && row < it.a_rows)
-        __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(it.db + row - it.a_row0), bsum[i], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)(row < it.split ? it.db + row - it.a_row0 : it.db2 + row - it.split),
+                               bsum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
