@@ -258,20 +258,33 @@ __global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __re
   }
 }
 
-// d(dirvec)^T(j, ray) = sum over the ray's samples of dh(j, ray*S + s)   (one wave per (row, ray)); both
-// buffers tile-major (common.h)
+// d(dirvec)^T(j, ray) = sum over the ray's samples of dh(j, ray*S + s); both buffers tile-major (common.h).
+// One workgroup per ray; a wave-load covers 8 rows x 32 samples of one tile (16 B per lane, 1 KiB per instruction),
+// the 8 lanes of a row are combined with three DPP-able shuffles.
 __global__ __launch_bounds__(256) void ray_sum_kernel(const float* __restrict__ dh, int dh_rows, int rows, int64_t n,
                                                       int S, float* __restrict__ out, int out_rows) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (int64_t)rows * n) return;
-  const int j = (int)(wid / n);
-  const int64_t ray = wid - (int64_t)j * n;
-  float s = 0.f;
-  for (int i = lane; i < S; i += 64) s += dh[tiled_index(j, ray * S + i, dh_rows)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t ray = blockIdx.x;
+  const int64_t m0 = ray * S, m1 = m0 + S;          // this ray's samples
+  const int64_t t0 = m0 >> 5, t1 = (m1 - 1) >> 5;   // tiles they live in
+  const int c4 = lane & 7, rsub = lane >> 3;
+  for (int rg = wave; rg * 8 < rows; rg += 4) {
+    const int row = rg * 8 + rsub;
+    float s = 0.f;
+    if (row < rows) {
+      for (int64_t t = t0; t <= t1; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dh + ((t * dh_rows + row) * 32 + 4 * c4));
+        const int64_t m = t * 32 + 4 * c4;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-  if (lane == 0) out[tiled_index(j, ray, out_rows)] = s;
+        for (int e = 0; e < 4; ++e)
+          if (m + e >= m0 && m + e < m1) s += v[e];
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (c4 == 0 && row < rows) out[tiled_index(row, ray, out_rows)] = s;
+  }
 }
 
 hipError_t launch_wgrad_f32(const WgradItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s) {
@@ -289,9 +302,8 @@ hipError_t launch_wgrad_f32(const WgradItem* d_items, const int32_t* d_first, in
 
 hipError_t launch_ray_sum(const float* dh, int dh_rows, int rows, int64_t n, int S, float* out, int out_rows,
                           hipStream_t s) {
-  const int64_t waves = (int64_t)rows * n;
-  hipLaunchKernelGGL(ray_sum_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, dh, dh_rows, rows, n, S, out,
-                     out_rows);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ray_sum_kernel, dim3((unsigned)n), dim3(256), 0, s, dh, dh_rows, rows, n, S, out, out_rows);
   return hipGetLastError();
 }
 
