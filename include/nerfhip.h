@@ -125,6 +125,13 @@ int nerfhip_render_dev(nerfhip_t* h, const float* rays_o, const float* rays_d, c
 int nerfhip_render_u8(nerfhip_t* h, const float* rays_o, const float* rays_d, const float* bounds,
                       const float* viewdir, int64_t n, uint8_t* out);
 
+/* One whole image from its camera pose: renderToImage (runNerf.scala:181-204) with the rays made on the device --
+ * getRaysNp + normalise + bounds (+ ndc) (getDataSet.scala:12-21,105-112; llff.scala:96-132) -> forward(eval) ->
+ * .mul(255).toType(UINT8).  c2w host [3][4]; out host [H][W][3] uint8, pixel (row j, col i) at j*W+i.  Any H*W:
+ * rendered in blocks of max_rays.  Replaces the H per-row evaluate calls and the upload of H*W*32 bytes of rays. */
+int nerfhip_render_pose_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w_host, float near,
+                           float far, int32_t ndc, uint8_t* out);
+
 /* ---- training ------------------------------------------------------------------------------- */
 /* trainer.forward(inputs) in training mode (runNerf.scala:100): fine and coarse rgb, [n][3] each
  * (rgb_coarse may be NULL; it is only produced when hierarchical). */

@@ -9,7 +9,7 @@ Mirrors, by name and meaning:
   BlenderRays          <- getDataSet.apply, dataSetType == "blender" (getDataSet.scala:46-65,67-171): white-background
                           blend images[..., :3] * a + (1 - a), near = 2, far = 6, rays of every pose through the
                           library's device ray generator (nerfhip_k_gen_rays == getRaysNp + normalise + bounds,
-                          bit-exact vs the oracle), flattened per split
+                          bit-exact in the GPU tests), flattened per split
   RayBatches           <- nerfDataSet (nerfDataSet.scala:11-74): one random permutation per epoch, consecutive slices of
                           batchNum rays, the last one short
 

@@ -173,6 +173,15 @@ class NerfBlock:
         o, d, b = flat(rays_o, 3), flat(rays_d, 3), flat(bounds, 2)
         return self.render_u8(o, d, b, d).reshape(P, H, W, 3)
 
+    def render_pose(self, H, W, focal, c2w, near, far, ndc=False):
+        """One image from its camera pose, rays generated on the device (nerfhip_render_pose_u8): uint8 (H, W, 3)."""
+        c2w = _f32(np.asarray(c2w)[:3, :4], (3, 4))
+        out = np.empty((H, W, 3), np.uint8)
+        rc = self._lib.nerfhip_render_pose_u8(self._h, int(H), int(W), float(focal), _ptr(c2w), float(near), float(far),
+                                              int(ndc), _ptr(out))
+        self._chk(rc, "render_pose_u8")
+        return out
+
     # ---- training (host arrays)
     def train_backward(self, rays_o, rays_d, bounds, view_dir, label, rand=None, debug=False):
         """trainer.forward + calculateLoss + collector.backward (runNerf.scala:100-103).

@@ -72,6 +72,8 @@ struct nerfhip {
   bool grads_ready = false;
   bool packed = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  float* d_pose_rays = nullptr;   // nerfhip_render_pose_u8: rays_o | rays_d | bounds of one frame
+  int64_t pose_rays_cap = 0;
   // workspace (device)
   float *w_o = nullptr, *w_d = nullptr, *w_b = nullptr, *w_v = nullptr, *w_label = nullptr;
   float *w_rgb_f = nullptr, *w_rgb_c = nullptr, *w_depth = nullptr, *w_acc = nullptr, *w_drgb = nullptr;
@@ -609,6 +611,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   fr(h->w_wf); fr(h->w_crawf); fr(h->w_trand); fr(h->w_urand); fr(h->w_noisec); fr(h->w_noisef); fr(h->w_u8);
   for (auto& r : h->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (auto e : h->ev_pool) hipEventDestroy(e);
+  if (h->d_pose_rays) hipFree(h->d_pose_rays);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -742,6 +745,32 @@ int nerfhip_render_u8(nerfhip_t* h, const float* o, const float* d, const float*
     HIPCHK(h, launch_to_u8(h->w_rgb_f, nr * 3, h->w_u8, h->stream));
     HIPCHK(h, hipMemcpyAsync(out + off * 3, h->w_u8, nr * 3, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return NERFHIP_OK;
+}
+
+int nerfhip_render_pose_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w, float near, float far,
+                           int32_t ndc, uint8_t* out) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!c2w || !out || H <= 0 || W <= 0 || !(focal > 0.f)) return fail(h, NERFHIP_E_INVALID, "render_pose_u8: bad argument");
+  const int64_t n = (int64_t)H * W;
+  if (h->pose_rays_cap < n) {   // frame-sized ray buffers, kept for the next frame of this size
+    if (h->d_pose_rays) { HIPCHK(h, hipFree(h->d_pose_rays)); h->d_pose_rays = nullptr; h->pose_rays_cap = 0; }
+    HIPCHK(h, hipMalloc((void**)&h->d_pose_rays, (size_t)n * 8 * sizeof(float)));
+    h->pose_rays_cap = n;
+  }
+  float* ro = h->d_pose_rays;
+  float* rd = ro + n * 3;
+  float* bd = rd + n * 3;
+  HIPCHK(h, launch_gen_rays(H, W, focal, c2w, near, far, ndc, ro, rd, bd, h->stream));
+  for (int64_t off = 0; off < n; off += h->R) {
+    const int64_t nr = std::min<int64_t>(h->R, n - off);
+    DevIn in{ro + off * 3, rd + off * 3, bd + off * 2, rd + off * 3, nullptr, nullptr, nullptr, nullptr};
+    rc = forward_dev(h, in, nr, false, false);
+    if (rc) return rc;
+    HIPCHK(h, launch_to_u8(h->w_rgb_f, nr * 3, h->w_u8, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out + off * 3, h->w_u8, nr * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // w_u8 is reused by the next block
   }
   return NERFHIP_OK;
 }

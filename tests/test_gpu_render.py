@@ -270,3 +270,24 @@ def test_errors_are_loud(G):
     rc = blk._lib.nerfhip_render_dev(blk._h, None, None, None, None, 4, None, None)
     assert rc == -1
     blk.close()
+
+
+@pytest.mark.parametrize("ndc", [False, True])
+def test_render_pose_matches_ray_level_render(G, ndc):
+    """nerfhip_render_pose_u8 (rays made on the device from the pose, rendered in max_rays blocks) == render_u8 on the
+    rays of k_gen_rays, byte for byte; pixel (j, i) at [j, i]; and within one grey level of the oracle's image."""
+    c = H.CONFIGS["small_dir"]
+    o = Oracle(c)
+    Hh, Ww, f = 23, 31, 40.0
+    th = 0.4
+    c2w = np.array([[np.cos(th), 0, np.sin(th), 0.3], [0, 1, 0, -0.1], [-np.sin(th), 0, np.cos(th), 3.8]], np.float32)
+    blk = G.make_block(c, max_rays=200)          # 713 rays -> 4 blocks, the last one short
+    blk.set_params(H.make_params(c, 4))
+    near, far = (0.0, 1.0) if ndc else (2.0, 6.0)
+    img = blk.render_pose(Hh, Ww, f, c2w, near, far, ndc)
+    assert img.shape == (Hh, Ww, 3) and img.dtype == np.uint8
+    eo, ed, eb = o.gen_rays(Hh, Ww, f, c2w, near, far, ndc)
+    np.testing.assert_array_equal(img.reshape(-1, 3), blk.render_u8(eo, ed, eb, ed))
+    ref = o.to_u8(o.forward(H.make_params(c, 4), eo, ed, eb, ed)["rgb_fine"]).reshape(Hh, Ww, 3)
+    assert np.abs(img.astype(int) - ref.astype(int)).max() <= 1
+    blk.close()
