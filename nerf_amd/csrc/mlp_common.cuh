@@ -238,7 +238,10 @@ __device__ __forceinline__ void relu_mask_words(const f32x16 (&a)[NT], uint32_t 
   for (int t = 0; t < NT; ++t) {
     if (t < nt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) w[t >> 1] |= (a[t][r] > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
+      for (int r = 0; r < 16; ++r) {   // "> 0" on the integer bits (same order as the floats'): clamp to 0/1, shift-or
+        const float x = a[t][r];        // (a temporary: bit_cast of a vector ELEMENT expression reads element 0 with this clang)
+        w[t >> 1] |= (uint32_t)min(max(__builtin_bit_cast(int, x), 0), 1) << (16 * (t & 1) + r);
+      }
     }
   }
 }
