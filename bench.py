@@ -291,6 +291,31 @@ def main():
                                    "frames": 1}})
         t5.close(); r5.close()
 
+    # ---- BASELINE configs[2] per GPU: one 800x800 frame straight from its camera pose (nerfhip_render_pose_u8: rays
+    # made on the device, rendered in max_rays blocks, uint8 image copied to the host) -- the PCIe-inclusive rate
+    def pose_frame(blk, frames=2):
+        hw8 = 800
+        f8 = 0.5 * hw8 / math.tan(0.5 * 0.6911112070083618)
+        blk.render_pose(hw8, hw8, f8, c2w, 2.0, 6.0, False)
+        torch.cuda.synchronize(); barrier()
+        t0_ = time.perf_counter()
+        for _ in range(frames):
+            blk.render_pose(hw8, hw8, f8, c2w, 2.0, 6.0, False)
+        d_ = time.perf_counter() - t0_
+        if world > 1:
+            t_ = torch.tensor([d_], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            d_ = float(t_.item())
+        return {"value": round(world * hw8 * hw8 * frames / d_, 1), "unit": "rays/s", "ms_per_frame": round(1e3 * d_ / frames, 2)}
+
+    render_pose = {"workload": "800x800 frame from (pose,H,W,f), uint8 image to host, per GPU", "f32": pose_frame(renderer, 1)}
+    if args.dtype == "f32" and not args.no_bf16_render:
+        rb2 = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype="bf16")))
+        rb2.set_stream(stream)
+        rb2.set_params(trainer.get_params())
+        render_pose["bf16"] = pose_frame(rb2, 3)
+        rb2.close()
+
     # ---- HBM-bound kernels on one frame's fine pass (160 000 rays x 192 samples): achieved GB/s on algorithmic bytes
     # (compositing fwd 24 B/sample, bwd 40 B/sample; resampling 8 B per coarse + 4 B per fine sample)
     def timed_kernel(fn, reps=10):
@@ -341,7 +366,8 @@ def main():
                            "parallelism": f"dp{world}"},
                 "samples_per_s": round(train_rays_s * 256, 1),
                 "roofline": roofline, "render": render, "render_bf16": render_bf16, "train_bf16": train_bf16,
-                "config5_bf16": config5, "hbm_kernels": hbm_kernels, "cpu_baseline": cpu}
+                "config5_bf16": config5, "render_pose_800": render_pose, "hbm_kernels": hbm_kernels,
+                "cpu_baseline": cpu}
         print(json.dumps(line))
     if dp:
         dist.destroy_process_group()
