@@ -100,6 +100,19 @@ class NerfBlock:
         m = _f32(m, (n,)); v = _f32(v, (n,))
         self._chk(self._lib.nerfhip_set_opt_state(self._h, _ptr(m), _ptr(v), n, int(step)), "set_opt_state")
 
+    # ---- checkpoints (the host owns the files; the reference only ever saves weights, runNerf.scala:125-131)
+    def save_checkpoint(self, path):
+        """weights + Adam moments + update count as one .npz (loadable with numpy, no pickle): true resume."""
+        m, v, step = self.get_opt_state()
+        np.savez(path, params=self.get_params(), adam_m=m, adam_v=v, step=np.int64(step),
+                 layout=np.array("flat fp32, DJL child order (include/nerfhip.h)"))
+
+    def load_checkpoint(self, path, weights_only=False):
+        with np.load(path, allow_pickle=False) as z:
+            self.set_params(z["params"])
+            if not weights_only:
+                self.set_opt_state(z["adam_m"], z["adam_v"], int(z["step"]))
+
     # ---- forward (host arrays)
     def _aux(self, n, rand, debug, training, keep):
         if not rand and not debug:

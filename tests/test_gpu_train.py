@@ -273,3 +273,35 @@ def test_fp32_other_network_shapes(G, variant):
     assert lf == pytest.approx(ref["loss_fine"], rel=1e-4)
     assert np.linalg.norm(gr - ref["grads"]) / np.linalg.norm(ref["grads"]) < 1e-3
     blk.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_checkpoint_resume(G, dtype, tmp_path):
+    """save_checkpoint / load_checkpoint (weights + Adam moments + update count): 3 steps, save, 3 more steps ==
+    a fresh handle that loads the file and runs the same 3 steps (fp32 atomics order is the only difference); a
+    weights-only load restarts Adam and therefore diverges."""
+    c = H.CONFIGS["small_dir"]
+    g = load("small_dir_train")
+    args = (g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"])
+    a = G.make_block(c, dtype=dtype)
+    a.set_params(H.make_params(c, 3))
+    for _ in range(3):
+        a.train_step(*args)
+    path = str(tmp_path / "ckpt.npz")
+    a.save_checkpoint(path)
+    for _ in range(3):
+        a.train_step(*args)
+    b = G.make_block(c, dtype=dtype)
+    b.load_checkpoint(path)
+    assert b.get_opt_state()[2] == 3
+    for _ in range(3):
+        b.train_step(*args)
+    np.testing.assert_allclose(b.get_params(), a.get_params(), rtol=0, atol=2e-6 if dtype == "f32" else 2e-4)
+    w = G.make_block(c, dtype=dtype)
+    w.load_checkpoint(path, weights_only=True)
+    assert w.get_opt_state()[2] == 0
+    for _ in range(3):
+        w.train_step(*args)
+    assert np.abs(w.get_params() - a.get_params()).max() > 1e-4
+    for blk in (a, b, w):
+        blk.close()
