@@ -179,181 +179,191 @@ def main():
               "roofline": {"kernel": "mlp_fwd", "bound": "mfma", "achieved": round(r_ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(r_ach / peak, 4)}}
 
-    # ---- bf16-MFMA render leg (BASELINE configs[4] arithmetic on the same frames; parity bar 1e-2 abs, tests/test_gpu_bf16.py)
-    render_bf16 = None
-    if args.dtype == "f32" and not args.no_bf16_render:
-        rb = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype="bf16")))
-        rb.set_stream(stream)
-        rb.set_params(trainer.get_params())
-        rb.render_dev(ro, rd, bd, rd, n_frame, out)
-        torch.cuda.synchronize(); barrier()
-        rb.set_profiling(True)
-        t0 = time.perf_counter()
-        for _ in range(args.render_frames):
+    # ---- everything below is extra reporting next to the headline numbers above; with one rank a failure in it is
+    # recorded in the line instead of losing the line (with several ranks it must propagate: the others would hang)
+    render_bf16 = train_bf16 = config5 = render_pose = hbm_kernels = cpu = None
+    extras_error = None
+    try:
+        # ---- bf16-MFMA render leg (BASELINE configs[4] arithmetic on the same frames; parity bar 1e-2 abs, tests/test_gpu_bf16.py)
+        render_bf16 = None
+        if args.dtype == "f32" and not args.no_bf16_render:
+            rb = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype="bf16")))
+            rb.set_stream(stream)
+            rb.set_params(trainer.get_params())
             rb.render_dev(ro, rd, bd, rd, n_frame, out)
-        torch.cuda.synchronize(); barrier()
-        dtb = time.perf_counter() - t0
-        bprof = rb.get_profile()
-        if world > 1:
-            t = torch.tensor([dtb], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtb = float(t.item())
-        b_ach = bprof["mlp_fwd_flop"] / max(bprof["mlp_fwd_ms"], 1e-9) / 1e9
-        render_bf16 = {"metric": "rays/sec (render, bf16 MFMA)", "value": round(world * n_frame * args.render_frames / dtb, 1),
-                       "unit": "rays/s", "dtype": "bf16", "ms_per_frame": round(1e3 * dtb / args.render_frames, 3),
-                       "roofline": {"kernel": "mlp_fwd_bf16", "bound": "mfma", "achieved": round(b_ach, 2),
-                                    "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                                    "frac": round(b_ach / PEAK_TFLOPS["bf16"], 4)},
-                       "hbm_kernels_ms_per_frame": {"composite": round(bprof["composite_ms"] / args.render_frames, 4),
-                                                    "sampling": round(bprof["sampling_ms"] / args.render_frames, 4)}}
-        rb.close()
+            torch.cuda.synchronize(); barrier()
+            rb.set_profiling(True)
+            t0 = time.perf_counter()
+            for _ in range(args.render_frames):
+                rb.render_dev(ro, rd, bd, rd, n_frame, out)
+            torch.cuda.synchronize(); barrier()
+            dtb = time.perf_counter() - t0
+            bprof = rb.get_profile()
+            if world > 1:
+                t = torch.tensor([dtb], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtb = float(t.item())
+            b_ach = bprof["mlp_fwd_flop"] / max(bprof["mlp_fwd_ms"], 1e-9) / 1e9
+            render_bf16 = {"metric": "rays/sec (render, bf16 MFMA)", "value": round(world * n_frame * args.render_frames / dtb, 1),
+                           "unit": "rays/s", "dtype": "bf16", "ms_per_frame": round(1e3 * dtb / args.render_frames, 3),
+                           "roofline": {"kernel": "mlp_fwd_bf16", "bound": "mfma", "achieved": round(b_ach, 2),
+                                        "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                        "frac": round(b_ach / PEAK_TFLOPS["bf16"], 4)},
+                           "hbm_kernels_ms_per_frame": {"composite": round(bprof["composite_ms"] / args.render_frames, 4),
+                                                        "sampling": round(bprof["sampling_ms"] / args.render_frames, 4)}}
+            rb.close()
 
-    # ---- bf16-MFMA training legs: the same batch (configs[3] arithmetic in bf16), and BASELINE configs[4]:
-    # 1024x1024 forward-facing scene, NDC rays (llff.scala:96-132), 64 + 256 samples per ray
-    def timed_train(blk, o_, d_, b_, l_, nsteps):
-        g = grad_tensor(blk) if dp else None
+        # ---- bf16-MFMA training legs: the same batch (configs[3] arithmetic in bf16), and BASELINE configs[4]:
+        # 1024x1024 forward-facing scene, NDC rays (llff.scala:96-132), 64 + 256 samples per ray
+        def timed_train(blk, o_, d_, b_, l_, nsteps):
+            g = grad_tensor(blk) if dp else None
 
-        def one():
-            if not dp:
-                blk.train_step_dev(o_, d_, b_, d_, l_, B)
-            else:
-                blk.train_backward_dev(o_, d_, b_, d_, l_, B)
-                dist.all_reduce(g)
-                blk.optimizer_step(1.0 / world)
-        for _ in range(args.warmup):
-            one()
-        torch.cuda.synchronize(); barrier()
-        blk.set_profiling(True)
-        t0_ = time.perf_counter()
-        for _ in range(nsteps):
-            one()
-        torch.cuda.synchronize(); barrier()
-        d_t = time.perf_counter() - t0_
-        pr = blk.get_profile()
-        blk.set_profiling(False)
-        if world > 1:
-            t_ = torch.tensor([d_t], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            d_t = float(t_.item())
-        ks = {"mlp_fwd": (pr["mlp_fwd_ms"], pr["mlp_fwd_flop"]), "mlp_bwd": (pr["mlp_bwd_ms"], pr["mlp_bwd_flop"]),
-              "mlp_wgrad": (pr["mlp_wgrad_ms"], pr["mlp_wgrad_flop"])}
-        return {"value": round(world * B * nsteps / d_t, 1), "unit": "rays/s", "dtype": "bf16", "steps": nsteps,
-                "ms_per_step": round(1e3 * d_t / nsteps, 3),
-                "kernel_ms_per_step": {k: round(v[0] / nsteps, 4) for k, v in ks.items()},
-                "kernel_tflops": {k: round(v[1] / max(v[0], 1e-9) / 1e9, 1) for k, v in ks.items()}}
+            def one():
+                if not dp:
+                    blk.train_step_dev(o_, d_, b_, d_, l_, B)
+                else:
+                    blk.train_backward_dev(o_, d_, b_, d_, l_, B)
+                    dist.all_reduce(g)
+                    blk.optimizer_step(1.0 / world)
+            for _ in range(args.warmup):
+                one()
+            torch.cuda.synchronize(); barrier()
+            blk.set_profiling(True)
+            t0_ = time.perf_counter()
+            for _ in range(nsteps):
+                one()
+            torch.cuda.synchronize(); barrier()
+            d_t = time.perf_counter() - t0_
+            pr = blk.get_profile()
+            blk.set_profiling(False)
+            if world > 1:
+                t_ = torch.tensor([d_t], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                d_t = float(t_.item())
+            ks = {"mlp_fwd": (pr["mlp_fwd_ms"], pr["mlp_fwd_flop"]), "mlp_bwd": (pr["mlp_bwd_ms"], pr["mlp_bwd_flop"]),
+                  "mlp_wgrad": (pr["mlp_wgrad_ms"], pr["mlp_wgrad_flop"])}
+            return {"value": round(world * B * nsteps / d_t, 1), "unit": "rays/s", "dtype": "bf16", "steps": nsteps,
+                    "ms_per_step": round(1e3 * d_t / nsteps, 3),
+                    "kernel_ms_per_step": {k: round(v[0] / nsteps, 4) for k, v in ks.items()},
+                    "kernel_tflops": {k: round(v[1] / max(v[0], 1e-9) / 1e9, 1) for k, v in ks.items()}}
 
-    train_bf16 = config5 = None
-    if args.dtype == "f32" and not args.no_bf16_train:
-        tb = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=B, dtype="bf16")))
-        tb.set_stream(stream)
-        tb.init_params(7)
-        train_bf16 = timed_train(tb, t_o, t_d, t_b, t_l, args.steps)
-        train_bf16["metric"] = "rays/sec (train step, bf16 MFMA)"
-        tb.close()
-        # config 5
-        HW5 = 1024
-        n5 = HW5 * HW5
-        c5 = dict(base, NImportance=256, dtype="bf16")
-        t5 = NerfBlock(NerfConfig.from_dict(dict(c5, maxRays=B)))
-        r5 = NerfBlock(NerfConfig.from_dict(dict(c5, maxRays=n5 // 4)))
-        t5.set_stream(stream); r5.set_stream(stream)
-        t5.init_params(7)
-        ro5, rd5, bd5 = torch.empty(n5, 3, **f32), torch.empty(n5, 3, **f32), torch.empty(n5, 2, **f32)
-        c2w5 = np.array([[1, 0, 0, 0.05 * rank], [0, 1, 0, 0.02], [0, 0, 1, 0.1]], np.float32)
-        r5.k_gen_rays(HW5, HW5, 0.9 * HW5, c2w5, 0.0, 1.0, True, ro5, rd5, bd5)
-        torch.cuda.synchronize()
-        lab5 = 0.5 + 0.5 * torch.sin(3.0 * rd5 + ro5)
-        idx5 = torch.randperm(n5, generator=gsel)[:B].cuda()
-        config5 = timed_train(t5, ro5[idx5].contiguous(), rd5[idx5].contiguous(), bd5[idx5].contiguous(),
-                              lab5[idx5].contiguous(), args.steps)
-        r5.set_params(t5.get_params())
-        out5 = torch.empty(n5, 3, **f32)
-        q = n5 // 4
+        train_bf16 = config5 = None
+        if args.dtype == "f32" and not args.no_bf16_train:
+            tb = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=B, dtype="bf16")))
+            tb.set_stream(stream)
+            tb.init_params(7)
+            train_bf16 = timed_train(tb, t_o, t_d, t_b, t_l, args.steps)
+            train_bf16["metric"] = "rays/sec (train step, bf16 MFMA)"
+            tb.close()
+            # config 5
+            HW5 = 1024
+            n5 = HW5 * HW5
+            c5 = dict(base, NImportance=256, dtype="bf16")
+            t5 = NerfBlock(NerfConfig.from_dict(dict(c5, maxRays=B)))
+            r5 = NerfBlock(NerfConfig.from_dict(dict(c5, maxRays=n5 // 4)))
+            t5.set_stream(stream); r5.set_stream(stream)
+            t5.init_params(7)
+            ro5, rd5, bd5 = torch.empty(n5, 3, **f32), torch.empty(n5, 3, **f32), torch.empty(n5, 2, **f32)
+            c2w5 = np.array([[1, 0, 0, 0.05 * rank], [0, 1, 0, 0.02], [0, 0, 1, 0.1]], np.float32)
+            r5.k_gen_rays(HW5, HW5, 0.9 * HW5, c2w5, 0.0, 1.0, True, ro5, rd5, bd5)
+            torch.cuda.synchronize()
+            lab5 = 0.5 + 0.5 * torch.sin(3.0 * rd5 + ro5)
+            idx5 = torch.randperm(n5, generator=gsel)[:B].cuda()
+            config5 = timed_train(t5, ro5[idx5].contiguous(), rd5[idx5].contiguous(), bd5[idx5].contiguous(),
+                                  lab5[idx5].contiguous(), args.steps)
+            r5.set_params(t5.get_params())
+            out5 = torch.empty(n5, 3, **f32)
+            q = n5 // 4
 
-        def frame5():
-            for k in range(4):   # a 1024x1024 frame in four 256-row blocks (workspace sized for one block)
-                sl = slice(k * q, (k + 1) * q)
-                r5.render_dev(ro5[sl], rd5[sl], bd5[sl], rd5[sl], q, out5[sl])
-        frame5()
-        torch.cuda.synchronize(); barrier()
-        t0 = time.perf_counter()
-        frame5()
-        torch.cuda.synchronize(); barrier()
-        dt5 = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt5], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt5 = float(t.item())
-        config5.update({"metric": "rays/sec (train step, bf16 MFMA, config 5)",
-                        "workload": "1024x1024 forward-facing scene, NDC rays, 64+256 samples/ray, 8x256 MLP",
-                        "samples_per_ray": 320,
-                        "render": {"value": round(world * n5 / dt5, 1), "unit": "rays/s", "ms_per_frame": round(1e3 * dt5, 2),
-                                   "frames": 1}})
-        t5.close(); r5.close()
+            def frame5():
+                for k in range(4):   # a 1024x1024 frame in four 256-row blocks (workspace sized for one block)
+                    sl = slice(k * q, (k + 1) * q)
+                    r5.render_dev(ro5[sl], rd5[sl], bd5[sl], rd5[sl], q, out5[sl])
+            frame5()
+            torch.cuda.synchronize(); barrier()
+            t0 = time.perf_counter()
+            frame5()
+            torch.cuda.synchronize(); barrier()
+            dt5 = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt5], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt5 = float(t.item())
+            config5.update({"metric": "rays/sec (train step, bf16 MFMA, config 5)",
+                            "workload": "1024x1024 forward-facing scene, NDC rays, 64+256 samples/ray, 8x256 MLP",
+                            "samples_per_ray": 320,
+                            "render": {"value": round(world * n5 / dt5, 1), "unit": "rays/s", "ms_per_frame": round(1e3 * dt5, 2),
+                                       "frames": 1}})
+            t5.close(); r5.close()
 
-    # ---- BASELINE configs[2] per GPU: one 800x800 frame straight from its camera pose (nerfhip_render_pose_u8: rays
-    # made on the device, rendered in max_rays blocks, uint8 image copied to the host) -- the PCIe-inclusive rate
-    def pose_frame(blk, frames=2):
-        hw8 = 800
-        f8 = 0.5 * hw8 / math.tan(0.5 * 0.6911112070083618)
-        blk.render_pose(hw8, hw8, f8, c2w, 2.0, 6.0, False)
-        torch.cuda.synchronize(); barrier()
-        t0_ = time.perf_counter()
-        for _ in range(frames):
+        # ---- BASELINE configs[2] per GPU: one 800x800 frame straight from its camera pose (nerfhip_render_pose_u8: rays
+        # made on the device, rendered in max_rays blocks, uint8 image copied to the host) -- the PCIe-inclusive rate
+        def pose_frame(blk, frames=2):
+            hw8 = 800
+            f8 = 0.5 * hw8 / math.tan(0.5 * 0.6911112070083618)
             blk.render_pose(hw8, hw8, f8, c2w, 2.0, 6.0, False)
-        d_ = time.perf_counter() - t0_
+            torch.cuda.synchronize(); barrier()
+            t0_ = time.perf_counter()
+            for _ in range(frames):
+                blk.render_pose(hw8, hw8, f8, c2w, 2.0, 6.0, False)
+            d_ = time.perf_counter() - t0_
+            if world > 1:
+                t_ = torch.tensor([d_], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                d_ = float(t_.item())
+            return {"value": round(world * hw8 * hw8 * frames / d_, 1), "unit": "rays/s", "ms_per_frame": round(1e3 * d_ / frames, 2)}
+
+        render_pose = {"workload": "800x800 frame from (pose,H,W,f), uint8 image to host, per GPU", "f32": pose_frame(renderer, 1)}
+        if args.dtype == "f32" and not args.no_bf16_render:
+            rb2 = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype="bf16")))
+            rb2.set_stream(stream)
+            rb2.set_params(trainer.get_params())
+            render_pose["bf16"] = pose_frame(rb2, 3)
+            rb2.close()
+
+        # ---- HBM-bound kernels on one frame's fine pass (160 000 rays x 192 samples): achieved GB/s on algorithmic bytes
+        # (compositing fwd 24 B/sample, bwd 40 B/sample; resampling 8 B per coarse + 4 B per fine sample)
+        def timed_kernel(fn, reps=10):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        S = 192
+        gk = torch.Generator(device="cuda").manual_seed(5)
+        sig = torch.rand(n_frame, S, generator=gk, **f32) * 3.0
+        crw = torch.randn(n_frame, S, 3, generator=gk, **f32)
+        zz = torch.sort(torch.rand(n_frame, S, generator=gk, **f32) * 4.0 + 2.0, dim=1).values.contiguous()
+        w_, rgb_, dep_, acc_ = torch.empty(n_frame, S, **f32), torch.empty(n_frame, 3, **f32), torch.empty(n_frame, **f32), torch.empty(n_frame, **f32)
+        drgb = torch.randn(n_frame, 3, generator=gk, **f32)
+        dsg, dcr = torch.empty(n_frame, S, **f32), torch.empty(n_frame, S, 3, **f32)
+        wc, zc = torch.rand(n_frame, 64, generator=gk, **f32), zz[:, ::3].contiguous()
+        zf = torch.empty(n_frame, 192, **f32)
+        ms_cf = timed_kernel(lambda: renderer.k_composite_fwd(sig, None, crw, zz, n_frame, S, w_, rgb_, dep_, acc_))
+        ms_cb = timed_kernel(lambda: renderer.k_composite_bwd(sig, None, crw, zz, drgb, n_frame, S, dsg, dcr))
+        ms_sp = timed_kernel(lambda: renderer.k_sample_pdf(wc, zc, None, n_frame, None, None, None, zf))
+        nsamp = n_frame * S
+
+        def hbm(ms, nbytes):
+            g = nbytes / ms / 1e6
+            return {"ms": round(ms, 4), "GB/s": round(g, 1), "frac_of_8TB/s": round(g / 8000.0, 3)}
+        hbm_kernels = {"workload": f"{n_frame} rays x {S} samples (resampling: 64 coarse -> 192 fine)",
+                       "composite_fwd": hbm(ms_cf, 24.0 * nsamp + 20.0 * n_frame),
+                       "composite_bwd": hbm(ms_cb, 40.0 * nsamp + 12.0 * n_frame),
+                       "sample_pdf": hbm(ms_sp, n_frame * (8.0 * 64 + 4.0 * 192))}
+        del sig, crw, zz, w_, dsg, dcr
+
+        cpu = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(base, t_o, t_d, t_b, t_l, args.cpu_seconds)
+
+    except Exception as e:   # noqa: BLE001
         if world > 1:
-            t_ = torch.tensor([d_], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            d_ = float(t_.item())
-        return {"value": round(world * hw8 * hw8 * frames / d_, 1), "unit": "rays/s", "ms_per_frame": round(1e3 * d_ / frames, 2)}
-
-    render_pose = {"workload": "800x800 frame from (pose,H,W,f), uint8 image to host, per GPU", "f32": pose_frame(renderer, 1)}
-    if args.dtype == "f32" and not args.no_bf16_render:
-        rb2 = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype="bf16")))
-        rb2.set_stream(stream)
-        rb2.set_params(trainer.get_params())
-        render_pose["bf16"] = pose_frame(rb2, 3)
-        rb2.close()
-
-    # ---- HBM-bound kernels on one frame's fine pass (160 000 rays x 192 samples): achieved GB/s on algorithmic bytes
-    # (compositing fwd 24 B/sample, bwd 40 B/sample; resampling 8 B per coarse + 4 B per fine sample)
-    def timed_kernel(fn, reps=10):
-        fn(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    S = 192
-    gk = torch.Generator(device="cuda").manual_seed(5)
-    sig = torch.rand(n_frame, S, generator=gk, **f32) * 3.0
-    crw = torch.randn(n_frame, S, 3, generator=gk, **f32)
-    zz = torch.sort(torch.rand(n_frame, S, generator=gk, **f32) * 4.0 + 2.0, dim=1).values.contiguous()
-    w_, rgb_, dep_, acc_ = torch.empty(n_frame, S, **f32), torch.empty(n_frame, 3, **f32), torch.empty(n_frame, **f32), torch.empty(n_frame, **f32)
-    drgb = torch.randn(n_frame, 3, generator=gk, **f32)
-    dsg, dcr = torch.empty(n_frame, S, **f32), torch.empty(n_frame, S, 3, **f32)
-    wc, zc = torch.rand(n_frame, 64, generator=gk, **f32), zz[:, ::3].contiguous()
-    zf = torch.empty(n_frame, 192, **f32)
-    ms_cf = timed_kernel(lambda: renderer.k_composite_fwd(sig, None, crw, zz, n_frame, S, w_, rgb_, dep_, acc_))
-    ms_cb = timed_kernel(lambda: renderer.k_composite_bwd(sig, None, crw, zz, drgb, n_frame, S, dsg, dcr))
-    ms_sp = timed_kernel(lambda: renderer.k_sample_pdf(wc, zc, None, n_frame, None, None, None, zf))
-    nsamp = n_frame * S
-
-    def hbm(ms, nbytes):
-        g = nbytes / ms / 1e6
-        return {"ms": round(ms, 4), "GB/s": round(g, 1), "frac_of_8TB/s": round(g / 8000.0, 3)}
-    hbm_kernels = {"workload": f"{n_frame} rays x {S} samples (resampling: 64 coarse -> 192 fine)",
-                   "composite_fwd": hbm(ms_cf, 24.0 * nsamp + 20.0 * n_frame),
-                   "composite_bwd": hbm(ms_cb, 40.0 * nsamp + 12.0 * n_frame),
-                   "sample_pdf": hbm(ms_sp, n_frame * (8.0 * 64 + 4.0 * 192))}
-    del sig, crw, zz, w_, dsg, dcr
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(base, t_o, t_d, t_b, t_l, args.cpu_seconds)
+            raise
+        extras_error = repr(e)
 
     if rank == 0:
         line = {"metric": "rays/sec (train step)", "value": round(train_rays_s, 1), "unit": "rays/s", "n_gpus": world,
@@ -367,7 +377,7 @@ def main():
                 "samples_per_s": round(train_rays_s * 256, 1),
                 "roofline": roofline, "render": render, "render_bf16": render_bf16, "train_bf16": train_bf16,
                 "config5_bf16": config5, "render_pose_800": render_pose, "hbm_kernels": hbm_kernels,
-                "cpu_baseline": cpu}
+                "cpu_baseline": cpu, "extras_error": extras_error}
         print(json.dumps(line))
     if dp:
         dist.destroy_process_group()
