@@ -91,6 +91,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C nerf_amd/csrc` "
                            "(or __graft_entry__.build()); nerf_amd has no fallback path")
+    # One HIP runtime per process: the PyTorch wheel carries its own libamdhip64.so, and whichever copy is mapped
+    # first serves every later user of that soname.  If this library came first it would bring in /opt/rocm's
+    # runtime, and torch, loaded afterwards on top of it, then finds no GPU ("No HIP GPUs are available").  Device
+    # tensors of the callers are torch's, so torch goes first when it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

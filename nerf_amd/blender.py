@@ -105,6 +105,7 @@ class BlenderRays:
             else:
                 images = images[..., :3]
         self.H, self.W, self.focal = H, W, focal
+        self.near, self.far, self.ndc = self.NEAR, self.FAR, False
         self.i_split = i_split
         self.block = block
         idx = {"train": range(0, i_split[0]), "val": range(i_split[0], i_split[1]), "test": range(i_split[1], i_split[2])}
@@ -116,6 +117,7 @@ class BlenderRays:
             self.splits[name] = (o, d, b, lab)
         self.render = self._rays(render_poses)
         self.poses, self.render_poses = poses, render_poses
+        self.split_poses = {name: poses[list(ids)] for name, ids in idx.items()}
 
     def _rays(self, poses):
         import torch

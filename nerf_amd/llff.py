@@ -155,6 +155,7 @@ class LlffRays:
             self.splits[name] = (o, d, b, lab)
         self.render = self._rays(render_poses)
         self.poses, self.render_poses, self.bds = poses, render_poses, bds
+        self.split_poses = {"train": poses[i_train], "test": poses[i_test], "val": poses[i_test]}
 
     def _rays(self, poses):
         import torch

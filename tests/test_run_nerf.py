@@ -1,0 +1,72 @@
+"""The host loop (nerf_amd/run_nerf.py <- nerf/runNerf.scala:22-204) on a tiny synthetic Blender scene.  The
+reference holds no fixture for its loop (parity unpinned); what is checked is the schedule the Scala code states
+(which step logs what, which validation image, the loss that is printed) and that the logged image is the render
+of the weights at that step."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from nerf_amd import NerfConfig
+from nerf_amd import run_nerf as R
+from test_blender_host import _make_scene
+
+
+def test_unknown_dataset_type_is_an_error(tmp_path):
+    run = R.RunConfig(dataSetType="deepvoxels", dataDir=str(tmp_path), logDir=str(tmp_path / "log"))
+    with pytest.raises(ValueError, match="not supported"):                      # getDataSet.scala:69
+        R.train(NerfConfig(), run)
+    assert not os.path.exists(tmp_path / "log")
+
+
+def test_run_config_mirrors_the_reference_defaults():
+    r = R.RunConfig()
+    assert (r.factor, r.llffHold, r.testSkip) == (8, 8, 1)                      # nerfConfig.scala:10-14
+    assert (r.iPrint, r.iImage, r.iWeight, r.iTestSet, r.iVideo, r.NIter) == (100, 500, 50000, 50000, 100000, 500000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["small_dir", "small_flat"])
+def test_train_loop_schedule(tmp_path, cfg_name):
+    from PIL import Image
+    scene = tmp_path / "scene"
+    _make_scene(str(scene))
+    cfg = NerfConfig.from_dict(H.CONFIGS[cfg_name])
+    cfg.batchNum, cfg.maxRays, cfg.seed = 64, 64, 1
+    run = R.RunConfig(dataSetType="blender", halfRes=False, testSkip=2, dataDir=str(scene), logDir=str(tmp_path / "log"),
+                      iPrint=2, iImage=3, iWeight=4, iTestSet=5, iVideo=6, NIter=6)
+    lines = []
+    res = R.train(cfg, run, log=lines.append, seed=0)
+    blk, ds = res["block"], res["data"]
+    try:
+        assert res["iters"] == 6
+        # 3 train images of 6 x 8 = 144 rays -> 3 batches per epoch (64, 64, 16): two epochs
+        assert [i for i, _ in res["train_loss"]] == [2, 4, 6] and all(np.isfinite(v) for _, v in res["train_loss"])
+        assert [i for i, _ in res["test_loss"]] == [5] and np.isfinite(res["test_loss"][0][1])
+        log = (tmp_path / "log" / "log.txt").read_text().splitlines()
+        assert log == lines and log[0] == "Train start." and log[-2:] == ["6 iterators: train over.", "Train over."]
+        assert "3 iterators: log image." in log and "4 iterators: save weight." in log and "6 iterators: log video." in log
+        # test set: 2 of 4 images (testSkip 2) = 96 rays -> 2 batches; iPrint = 2 -> one partial line, then the mean
+        assert sum(l.startswith("2 iterators test: loss is ") for l in log) == 1
+        assert any(l.startswith("Test over, mean loss is ") for l in log)
+        assert sorted(os.listdir(tmp_path / "log" / "imageLogs")) == ["3.png", "6.png"]
+        assert os.listdir(tmp_path / "log" / "weightLogs") == ["4.npz"]
+        assert len(os.listdir(tmp_path / "log" / "videoLogs" / "6")) == 40      # blender.scala:145: 40 render poses
+        # image logged at step 6 = validation image (6 / 3 - 1) mod 1 = 0, rendered with the final weights
+        assert len(ds.split_poses["val"]) == 1
+        got = np.asarray(Image.open(tmp_path / "log" / "imageLogs" / "6.png"))
+        want = blk.render_pose(ds.H, ds.W, ds.focal, ds.split_poses["val"][0], 2.0, 6.0, False)
+        assert got.shape == (6, 8, 3)
+        np.testing.assert_array_equal(got, want)
+        # and equals the row-by-row path over the data set's own rays (renderToImage, runNerf.scala:187-199)
+        o, d, b, _ = ds.splits["val"]
+        rows = blk.render_to_image(o.cpu().numpy().reshape(1, 6, 8, 3), d.cpu().numpy().reshape(1, 6, 8, 3),
+                                   b.cpu().numpy().reshape(1, 6, 8, 2))[0]
+        np.testing.assert_array_equal(rows, want)
+        # the checkpoint of step 4 resumes: loading it and replaying steps 5 and 6 is covered in test_gpu_train.py;
+        # here: it holds the update count
+        with np.load(tmp_path / "log" / "weightLogs" / "4.npz") as z:
+            assert int(z["step"]) == 4 and z["params"].size == blk.param_count()
+    finally:
+        blk.close()
