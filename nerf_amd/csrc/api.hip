@@ -476,7 +476,7 @@ int check_handle(nerfhip* h) {
 
 extern "C" {
 
-const char* nerfhip_version(void) { return "nerfhip 0.1 (gfx950, fp32 MFMA)"; }
+const char* nerfhip_version(void) { return "nerfhip 0.1 (gfx950, fp32 and bf16 MFMA)"; }
 
 const char* nerfhip_last_error(const nerfhip_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 

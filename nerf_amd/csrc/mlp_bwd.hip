@@ -142,11 +142,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
     // part, mlp_common.cuh) and then runs through the whole stream.  The head chunks are walked even without a
     // colour gradient (dh = 0 then), which keeps the control flow free of un-primed paths.
     prime_frags(fr, wp, fvoff);
-    mm_layer_g<WT, R, 1>(acc, &dh[0], fr, wp, fvoff, StoreSide<1, WT>{&dh[0], dhb, voff});
+    mm_layer_g<WT, R, 1, true>(acc, &dh[0], fr, wp, fvoff, StoreSide<1, WT>{&dh[0], dhb, voff});
 #pragma unroll
     for (int kt = 1; kt < HTM; ++kt)
       if (kt < HT)
-        mm_layer_g<WT, R, 1>(acc, &dh[kt], fr, wp + kt * 32 * R, fvoff, StoreSide<1, WT>{&dh[kt], dhb + kt * 1024, voff});
+        mm_layer_g<WT, R, 1, true>(acc, &dh[kt], fr, wp + kt * 32 * R, fvoff, StoreSide<1, WT>{&dh[kt], dhb + kt * 1024, voff});
   } else {
     store_dh();
     if (has_rgb) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       if constexpr (kFast) {
         const BwdSide<WT> side{{g, dy, voff}, st.mask + (int64_t)((l - 1) * 8) * Mp, mnext, Mp, mvoff};
-        mm_layer_g<WT, R, WT>(acc, g, fr, wp, fvoff, side);
+        mm_layer_g<WT, R, WT, true>(acc, g, fr, wp, fvoff, side);
       } else {
 #pragma unroll
         for (int w = 0; w < NW; ++w) mnext[w] = *mask_ptr(st.mask, l - 1, h, w, Mp, m);
