@@ -90,8 +90,7 @@ def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None):
         raise ValueError(f"Dataset type {run.dataSetType!r} not supported")
     if cfg.maxRays < cfg.batchNum:
         cfg.maxRays = cfg.batchNum
-    own = block is None
-    if own:
+    if block is None:
         block = NerfBlock(cfg)
         block.init_params(cfg.seed)
     ds = get_data_set(block, cfg, run)

@@ -70,3 +70,33 @@ def test_train_loop_schedule(tmp_path, cfg_name):
             assert int(z["step"]) == 4 and z["params"].size == blk.param_count()
     finally:
         blk.close()
+
+
+@pytest.mark.gpu
+def test_train_loop_llff_ndc(tmp_path):
+    """The llff branch (getDataSet.scala:28-45): NDC rays, llffHold split, 120 spiral poses; 9 images of 12 x 16."""
+    from PIL import Image
+    from test_llff_host import _make_scene as make_llff
+    scene = tmp_path / "scene"
+    os.makedirs(scene)
+    make_llff(str(scene))
+    cfg = NerfConfig.from_dict(H.CONFIGS["small_dir"])
+    cfg.batchNum, cfg.maxRays, cfg.seed, cfg.ndc = 256, 256, 2, True
+    run = R.RunConfig(dataSetType="llff", factor=2, llffHold=4, dataDir=str(scene), logDir=str(tmp_path / "log"),
+                      iPrint=2, iImage=2, iWeight=100, iTestSet=4, iVideo=100, NIter=4)
+    res = R.train(cfg, run, seed=0)
+    blk, ds = res["block"], res["data"]
+    try:
+        # images 0, 4, 8 are held out (test = val); 6 train images of 192 rays = 1152 rays -> 5 batches per epoch
+        assert ds.i_test == [0, 4, 8] and len(ds.i_train) == 6 and ds.ndc
+        assert res["iters"] == 4 and [i for i, _ in res["train_loss"]] == [2, 4]
+        assert len(res["test_loss"]) == 1 and np.isfinite(res["test_loss"][0][1])
+        assert sorted(os.listdir(tmp_path / "log" / "imageLogs")) == ["2.png", "4.png"]
+        # step 4 logs validation image (4 / 2 - 1) mod 3 = 1, i.e. pose 4, from NDC rays with bounds (0, |d'|)
+        got = np.asarray(Image.open(tmp_path / "log" / "imageLogs" / "4.png"))
+        want = blk.render_pose(ds.H, ds.W, ds.focal, ds.split_poses["val"][1], ds.near, ds.far, True)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(ds.split_poses["val"][1], ds.poses[4])
+        assert ds.render_poses.shape == (120, 3, 4)
+    finally:
+        blk.close()
