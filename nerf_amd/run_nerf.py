@@ -15,8 +15,11 @@ Mirrors, by name and meaning:
                       calls trainer.forward there, :144, so raw noise and the coarse colour head are on); every iVideo
                       steps all render poses as PNGs; stops after NIter steps
 Differences, on purpose: log lines also go to `log` (the reference redirects stdout into logDir/log.txt, :84-85);
-weights are saved as .npz with the Adam state (NerfBlock.save_checkpoint) instead of DJL's parameter stream; with
-several ranks the loop is the same per rank with nerf_amd.dp.DataParallel around the step (bench.py shows it).
+weights are saved as .npz with the Adam state (NerfBlock.save_checkpoint) instead of DJL's parameter stream.
+Several devices (`config.device` with more than one entry, `next.split(devices)`, :95): one process per GPU, each
+calls train(..., dp=DataParallel.for_block(block), seed=<same on every rank>) after dp.shared_stream(block); every
+rank draws the same permutation, takes its slice of each batch (split_batch), the gradients are all-reduced once per
+step (nerf_amd/dp.py), rank 0 alone writes logs, images and weights.
 """
 import os
 from dataclasses import dataclass
@@ -83,27 +86,56 @@ def eval_test_set(block, ds, batch_num, i_print, log):
     return mean
 
 
-def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None):
+def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None, dp=None):
     """runNerf.train.  Returns {"block", "data", "iters", "train_loss": [(idx, mean)], "test_loss": [(idx, mean)]};
-    the caller closes the block."""
+    the caller closes the block.  `dp`: a nerf_amd.dp.DataParallel for this rank's block (module docstring)."""
     if run.dataSetType not in ("blender", "llff"):
         raise ValueError(f"Dataset type {run.dataSetType!r} not supported")
+    rank, world = (dp.rank, dp.world) if dp is not None else (0, 1)
+    if world > 1 and seed is None:
+        raise ValueError("data-parallel training needs a seed: every rank must draw the same permutations")
     if cfg.maxRays < cfg.batchNum:
         cfg.maxRays = cfg.batchNum
     if block is None:
         block = NerfBlock(cfg)
         block.init_params(cfg.seed)
+    if dp is not None:
+        dp.broadcast_params(block.get_params, block.set_params)
     ds = get_data_set(block, cfg, run)
     dirs = {k: os.path.join(run.logDir, k) for k in ("imageLogs", "weightLogs", "videoLogs")}
-    for p in dirs.values():
-        os.makedirs(p, exist_ok=True)
-    logf = open(os.path.join(run.logDir, "log.txt"), "w")
+    if rank == 0:
+        for p in dirs.values():
+            os.makedirs(p, exist_ok=True)
+    logf = open(os.path.join(run.logDir, "log.txt"), "w") if rank == 0 else None
 
     def say(line):
+        if rank != 0:
+            return
         logf.write(line + "\n")
         logf.flush()
         if log is not None:
             log(line)
+
+    def step(o, d, b, lab):
+        if dp is None:
+            block.train_step_dev(o, d, b, d, lab, int(o.shape[0]), loss)             # viewDir = raysD (:99)
+            return
+        from .dp import split_batch
+        i0, i1 = split_batch(int(o.shape[0]), rank, world)                            # next.split(devices, false) (:95)
+        if i1 > i0:
+            dp.train_step(lambda: block.train_backward_dev(o[i0:i1], d[i0:i1], b[i0:i1], d[i0:i1], lab[i0:i1], i1 - i0, loss))
+        else:                                                                          # fewer rays than ranks: contribute zeros
+            loss[:] = 0
+            dp.train_step(lambda: dp.grad_view().zero_())
+
+    def mean_over_ranks(x):
+        if world == 1:
+            return x
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(x)], device=f"cuda:{cfg.device}")
+        dist.all_reduce(t, group=dp.group)
+        return np.float32(t.item() / world)                                            # lossValue / splits.length (:102)
 
     hier = cfg.useHierarchical
     val_poses = ds.split_poses["val"]
@@ -118,29 +150,28 @@ def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None):
             for (o, d, b), lab in batches:
                 if stop:
                     break
-                block.train_step_dev(o.contiguous(), d.contiguous(), b.contiguous(), d.contiguous(), lab.contiguous(),
-                                     int(o.shape[0]), loss)                      # viewDir = raysD (:99)
+                step(o.contiguous(), d.contiguous(), b.contiguous(), lab.contiguous())
                 block.synchronize()                                              # lossValue.getFloat() (:102)
                 loss_sum += loss[0] + (loss[1] if hier else np.float32(0))
                 idx += 1
                 if idx % run.iPrint == 0:
-                    mean = float(loss_sum / np.float32(run.iPrint))
+                    mean = float(mean_over_ranks(loss_sum) / np.float32(run.iPrint))
                     say(f"{idx} iterators train: loss is {mean}.")
                     out["train_loss"].append((idx, mean))
                     loss_sum = np.float32(0)
-                if idx % run.iImage == 0 and len(val_poses):
+                if rank == 0 and idx % run.iImage == 0 and len(val_poses):
                     who = (idx // run.iImage - 1) % len(val_poses)
                     say(f"{idx} iterators: log image.")
                     _save_png(os.path.join(dirs["imageLogs"], f"{idx}.png"), render_to_image(block, ds, val_poses[who:who + 1])[0])
                     say("Log over.")
-                if idx % run.iWeight == 0:
+                if rank == 0 and idx % run.iWeight == 0:
                     say(f"{idx} iterators: save weight.")
                     block.save_checkpoint(os.path.join(dirs["weightLogs"], f"{idx}.npz"))
                     say("Log over.")
-                if idx % run.iTestSet == 0:
+                if rank == 0 and idx % run.iTestSet == 0:
                     say(f"{idx} iterators: start to test.")
                     out["test_loss"].append((idx, eval_test_set(block, ds, cfg.batchNum, run.iPrint, say)))
-                if idx % run.iVideo == 0:
+                if rank == 0 and idx % run.iVideo == 0:
                     say(f"{idx} iterators: log video.")
                     path = os.path.join(dirs["videoLogs"], str(idx))
                     os.makedirs(path, exist_ok=True)
@@ -152,7 +183,8 @@ def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None):
                     stop = True
         say("Train over.")
     finally:
-        logf.close()
+        if logf is not None:
+            logf.close()
     out["iters"] = idx
     return out
 

@@ -100,3 +100,45 @@ def test_train_loop_llff_ndc(tmp_path):
         assert ds.render_poses.shape == (120, 3, 4)
     finally:
         blk.close()
+
+
+@pytest.mark.gpu
+def test_train_loop_with_data_parallel_wrapper(tmp_path):
+    """train(..., dp=...) at world size 1 (explicit stream, backward / all-reduce slot / optimizer step as separate
+    calls) follows the same trajectory as the fused single-device step; world size 2 of the same wrapper runs on
+    gloo in tests/test_dp_gloo.py."""
+    import torch
+    from nerf_amd import NerfBlock
+    from nerf_amd.dp import DataParallel, shared_stream
+    scene = tmp_path / "scene"
+    _make_scene(str(scene))
+    out = []
+    for use_dp in (False, True):
+        cfg = NerfConfig.from_dict(H.CONFIGS["small_dir"])
+        cfg.batchNum, cfg.maxRays, cfg.seed = 64, 64, 1
+        run = R.RunConfig(dataSetType="blender", halfRes=False, testSkip=2, dataDir=str(scene),
+                          logDir=str(tmp_path / f"log{int(use_dp)}"), iPrint=1, iImage=100, iWeight=100, iTestSet=100,
+                          iVideo=100, NIter=5)
+        blk = NerfBlock(cfg)
+        blk.init_params(cfg.seed)
+        prev = torch.cuda.current_stream()
+        try:
+            dp = None
+            if use_dp:
+                shared_stream(blk)
+                dp = DataParallel.for_block(blk)
+            res = R.train(cfg, run, block=blk, seed=3, dp=dp)
+            out.append(([v for _, v in res["train_loss"]], blk.get_params()))
+        finally:
+            torch.cuda.set_stream(prev)
+            blk.close()
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-4)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=2e-5)
+
+
+def test_data_parallel_needs_a_seed(tmp_path):
+    class FakeDp:
+        rank, world, group = 1, 2, None
+    run = R.RunConfig(dataSetType="blender", dataDir=str(tmp_path), logDir=str(tmp_path / "log"))
+    with pytest.raises(ValueError, match="seed"):
+        R.train(NerfConfig(), run, dp=FakeDp())
