@@ -1,0 +1,99 @@
+"""Two ranks on ONE GPU (gloo carrying the device gradient buffer): the data-parallel product path end to end --
+NerfBlock on an explicit stream, nerf_amd.dp.DataParallel around the step, the run loop's batch slicing -- against
+a single-process run of the same batches.  RCCL needs one GPU per rank, so on the one-GPU box the collective goes
+through gloo (which stages device tensors through the host); the 8-GPU RCCL run is the driver's.  Skips if this
+torch build's gloo cannot reduce device tensors."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg():
+    from nerf_amd import NerfConfig
+    cfg = NerfConfig.from_dict(H.CONFIGS["small_dir"])
+    cfg.batchNum, cfg.maxRays, cfg.seed = 64, 64, 1
+    return cfg
+
+
+def _run(scene, logdir):
+    from nerf_amd import run_nerf as R
+    return R.RunConfig(dataSetType="blender", halfRes=False, testSkip=2, dataDir=scene, logDir=logdir, iPrint=1,
+                       iImage=100, iWeight=100, iTestSet=100, iVideo=100, NIter=6)
+
+
+def _worker(rank, world, port, scene, outdir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        try:
+            t = torch.ones(4, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            ok = bool((t == world).all().item())
+        except Exception:
+            ok = False
+        if not ok:
+            open(os.path.join(outdir, f"unsupported{rank}"), "w").close()
+            return
+        from nerf_amd import NerfBlock
+        from nerf_amd import run_nerf as R
+        from nerf_amd.dp import DataParallel, shared_stream
+        cfg = _cfg()
+        blk = NerfBlock(cfg)
+        blk.init_params(cfg.seed + rank)            # different on purpose: train() broadcasts rank 0's parameters
+        shared_stream(blk)
+        dp = DataParallel.for_block(blk)
+        res = R.train(cfg, _run(scene, os.path.join(outdir, "log_dp")), block=blk, seed=3, dp=dp)
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), params=blk.get_params(),
+                 losses=np.array([v for _, v in res["train_loss"]], np.float64))
+        blk.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_match_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from nerf_amd import NerfBlock
+    from nerf_amd import run_nerf as R
+    from test_blender_host import _make_scene
+    scene = str(tmp_path / "scene")
+    _make_scene(scene)
+    port = 29500 + os.getpid() % 2000
+    ctx = mp.spawn(_worker, args=(2, port, scene, str(tmp_path)), nprocs=2, join=False)
+    deadline = time.time() + 100
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.terminate()
+            pytest.fail("data-parallel ranks did not finish in 100 s")
+    if os.path.exists(tmp_path / "unsupported0") or os.path.exists(tmp_path / "unsupported1"):
+        pytest.skip("gloo in this torch build cannot all-reduce device tensors")
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["params"], r1["params"])          # replicas stay identical
+    np.testing.assert_array_equal(r0["losses"], r1["losses"])          # the printed loss is the mean over ranks
+    # rank 0 alone wrote the log
+    log = (tmp_path / "log_dp" / "log.txt").read_text().splitlines()
+    assert log[0] == "Train start." and log[-1] == "Train over." and sum("iterators train" in l for l in log) == 6
+    # one process, whole batches, same permutations: the same trajectory up to summation order
+    cfg = _cfg()
+    blk = NerfBlock(cfg)
+    blk.init_params(cfg.seed)
+    try:
+        res = R.train(cfg, _run(scene, str(tmp_path / "log_one")), block=blk, seed=3)
+        np.testing.assert_allclose(r0["losses"], [v for _, v in res["train_loss"]], rtol=1e-4)
+        np.testing.assert_allclose(r0["params"], blk.get_params(), rtol=0, atol=2e-5)
+    finally:
+        blk.close()
