@@ -73,6 +73,9 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
+    def note(msg):   # progress on stderr (stdout carries exactly one JSON line)
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     # one explicit stream for the library's kernels, torch's tensor ops and (through torch) the RCCL collectives:
     # the all-reduce is ordered after the backward kernels and the Adam kernel after the all-reduce on it
     tstream = torch.cuda.Stream(device=local)
@@ -123,9 +126,11 @@ def main():
         if dp:
             dist.barrier()
 
+    note("set up")
     for _ in range(args.warmup):
         train_step()
     torch.cuda.synchronize(); barrier()
+    note("warm-up done")
     trainer.set_profiling(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -140,6 +145,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     train_rays_s = world * B * args.steps / dt
+    note("train leg done")
 
     # ---- render leg: whole 400x400 frames, ray-parallel, no collective
     out = torch.empty(n_frame, 3, **f32)
@@ -158,6 +164,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dtr = float(t.item())
     render_rays_s = world * n_frame * args.render_frames / dtr
+    note("render leg done")
 
     # ---- roofline of the dominant kernel of the timed train region (HIP events on the launch stream)
     kern = {"mlp_fwd": (prof["mlp_fwd_ms"], prof["mlp_fwd_flop"]), "mlp_bwd": (prof["mlp_bwd_ms"], prof["mlp_bwd_flop"]),
@@ -212,6 +219,7 @@ def main():
                            "hbm_kernels_ms_per_frame": {"composite": round(bprof["composite_ms"] / args.render_frames, 4),
                                                         "sampling": round(bprof["sampling_ms"] / args.render_frames, 4)}}
             rb.close()
+            note("bf16 render leg done")
 
         # ---- bf16-MFMA training legs: the same batch (configs[3] arithmetic in bf16), and BASELINE configs[4]:
         # 1024x1024 forward-facing scene, NDC rays (llff.scala:96-132), 64 + 256 samples per ray
@@ -255,6 +263,7 @@ def main():
             train_bf16 = timed_train(tb, t_o, t_d, t_b, t_l, args.steps)
             train_bf16["metric"] = "rays/sec (train step, bf16 MFMA)"
             tb.close()
+            note("bf16 train leg done")
             # config 5
             HW5 = 1024
             n5 = HW5 * HW5
