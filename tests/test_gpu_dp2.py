@@ -71,12 +71,14 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path):
     scene = str(tmp_path / "scene")
     _make_scene(scene)
     port = 29500 + os.getpid() % 2000
-    ctx = mp.spawn(_worker, args=(2, port, scene, str(tmp_path)), nprocs=2, join=False)
+    ctx = mp.spawn(_worker, args=(2, port, scene, str(tmp_path)), nprocs=2, join=False, daemon=True)
     deadline = time.time() + 60
     while not ctx.join(timeout=5):
         if time.time() > deadline:
             for p in ctx.processes:
-                p.terminate()
+                p.kill()
+            for p in ctx.processes:
+                p.join(timeout=10)
             # torch's gloo backend can stall on device tensors when two processes share a GPU -- reproduced with plain
             # torch code and no nerfhip in the process (scripts/gloo_probe.py stalls at its third 4 MB all-reduce), so a
             # stall here says nothing about the product path and must not stop the rest of the suite
