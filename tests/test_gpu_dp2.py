@@ -80,7 +80,7 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path):
             for p in ctx.processes:
                 p.join(timeout=10)
             # torch's gloo backend can stall on device tensors when two processes share a GPU -- reproduced with plain
-            # torch code and no nerfhip in the process (scripts/gloo_probe.py stalls at its third 4 MB all-reduce), so a
+            # torch code and no nerfhip in the process (scripts/gloo_probe.py stalls within its first three all-reduces when both ranks keep the GPU busy), so a
             # stall here says nothing about the product path and must not stop the rest of the suite
             pytest.skip("gloo all-reduce of device tensors stalled on the shared GPU (scripts/gloo_probe.py)")
     if os.path.exists(tmp_path / "unsupported0") or os.path.exists(tmp_path / "unsupported1"):
