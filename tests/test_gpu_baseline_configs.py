@@ -1,0 +1,72 @@
+"""BASELINE.json configs that are parity cases rather than bench lines.
+
+configs[0]  "Tiny NeRF, synthetic Blender-format scene 100x100, 64 coarse samples/ray, no hierarchical pass,
+            reference CPU path": a whole 100x100 frame from its pose on the GPU against the CPU oracle.
+configs[2]  "Full NeRF render of 800x800 Blender-style scene, rays sharded across 8 GPUs": the row-block sharding
+            of nerf_amd/dp.py -- eight ranks' blocks rendered one after the other on the one GPU here, stitched in
+            rank order -- equals the unsharded frame bit for bit (rays are independent; no collective on this path).
+configs[1], [3], [4] are the bench legs (bench.py) and have their parity tests in test_gpu_render / _train / _bf16."""
+import math
+
+import numpy as np
+import pytest
+
+import gpu_util as G
+import helpers as H
+from nerf_amd import blender as B
+from nerf_amd.dp import row_block
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+ANGLE = 0.6911112070083618
+
+
+def test_config0_tiny_frame_matches_cpu_path():
+    c = H.cfg(D=4, W=64, skips=[2], posL=6, dirL=2, NSamples=64, NImportance=0, useHierarchical=False)
+    HW = 100
+    focal = 0.5 * HW / math.tan(0.5 * ANGLE)
+    pose = B.get_render_poses(0.9, math.pi / 6, 4.0)
+    o = Oracle(c)
+    params = H.make_params(c, 5)
+    ro, rd, bd = o.gen_rays(HW, HW, focal, pose, 2.0, 6.0, False)
+    ref = o.forward(params, ro, rd, bd, rd)["rgb_fine"]                       # the CPU path, 10 000 rays
+    blk = G.make_block(c, max_rays=4096)
+    blk.set_params(params)
+    try:
+        img = blk.render_pose(HW, HW, focal, pose, 2.0, 6.0, False)           # rays generated on the device
+        rgb = blk.evaluate(ro, rd, bd, rd)
+        np.testing.assert_allclose(rgb, ref, rtol=0, atol=2e-4)
+        np.testing.assert_array_equal(img.reshape(-1, 3), o.to_u8(rgb))       # pixel (j, i) at j*W + i, x255 truncated
+        want = o.to_u8(ref).astype(np.int16)
+        diff = np.abs(img.reshape(-1, 3).astype(np.int16) - want)
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.99                  # a 2e-4 difference can cross an integer
+    finally:
+        blk.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_config2_row_sharded_frame_equals_whole_frame(dtype):
+    c = dict(H.CONFIGS["full"], dtype=dtype)
+    Himg, Wimg, world = 800, 16, 8                 # all 800 rows (the sharded axis) of a 16-pixel-wide strip
+    focal = 0.5 * 800 / math.tan(0.5 * ANGLE)
+    pose = B.get_render_poses(2.1, math.pi / 6, 4.0)
+    blk = G.make_block(c, max_rays=4096)
+    blk.init_params(3)
+    try:
+        n = Himg * Wimg
+        ro, rd, bd = G.empty(n, 3), G.empty(n, 3), G.empty(n, 2)
+        blk.k_gen_rays(Himg, Wimg, focal, pose, 2.0, 6.0, False, ro, rd, bd)
+        blk.synchronize()
+        ro, rd, bd = ro.cpu().numpy(), rd.cpu().numpy(), bd.cpu().numpy()
+        whole = blk.render_u8(ro, rd, bd, rd).reshape(Himg, Wimg, 3)
+        parts, rows = [], 0
+        for rank in range(world):
+            r0, r1 = row_block(Himg, rank, world)
+            assert r1 - r0 == 100 and r0 == rows                             # contiguous blocks of 100 rows
+            s = slice(r0 * Wimg, r1 * Wimg)
+            parts.append(blk.render_u8(ro[s], rd[s], bd[s], rd[s]).reshape(r1 - r0, Wimg, 3))
+            rows = r1
+        np.testing.assert_array_equal(np.concatenate(parts, 0), whole)
+    finally:
+        blk.close()
