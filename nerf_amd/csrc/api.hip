@@ -17,7 +17,8 @@
 using namespace nh;
 
 namespace {
-std::string g_create_error;
+// text of the last failed nerfhip_create of THIS thread (a failed create has no handle to carry it)
+thread_local std::string g_create_error;
 
 struct Net {
   NetLayout L{};
@@ -348,7 +349,7 @@ int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const floa
     bst.Mpad = (nr * S + 255) / 256 * 256;
     HIPCHK(h, launch_mlp_fwd_bf16(train_store ? &bst : nullptr, net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z, n.d_dirfeat,
                                   nr * S, S, sigma, craw, want_rgb ? 1 : 0,
-                                  (int)((want_rgb ? n.bf_full.size() : n.bf_sigma.size()) / 32), h->stream));
+                                  (int)((want_rgb ? n.bf_full.size() : n.bf_sigma.size()) / 32), h->n_cu, h->stream));
   } else {
     ActStore st = n.st;
     st.Mpad = (nr * S + kTile - 1) / kTile * kTile;
@@ -503,6 +504,13 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
     if ((long long)c.max_rays * smax >= (1LL << 31)) return bad("dtype bf16: max_rays x samples per ray must be < 2^31");
   }
   if (c.lrate_decay <= 0) return bad("lrateDecay must be > 0");
+  { // per-ray kernels stage one ray per wave in at most 64 KiB of LDS per 4-wave workgroup (ray_kernels.hip)
+    const int S_all = c.use_hierarchical ? c.n_samples + c.n_importance : c.n_samples;
+    if (composite_bwd_lds_bytes(S_all) > 64 * 1024)
+      return bad("NSamples + NImportance too large for the compositing backward kernel (48 B of LDS per sample, 64 KiB)");
+    if (c.use_hierarchical && sample_pdf_lds_bytes(c.n_samples, c.n_importance, c.perturb) > 64 * 1024)
+      return bad("NSamples / NImportance too large for the resampling kernel (CDF, bins and sort buffer must fit 64 KiB of LDS)");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(nullptr, NERFHIP_E_HIP, "no HIP device available (libnerfhip has no CPU path)");
@@ -524,6 +532,13 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
   do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                                      \
       return cleanup_fail(e_ == hipErrorOutOfMemory ? NERFHIP_E_NOMEM : NERFHIP_E_HIP,                    \
                           std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+  // kernels with > 64 KiB of dynamic LDS: raise the limit on THIS device (per handle, not per process)
+  CCHK(prepare_wgrad_f32());
+  if (c.dtype == NERFHIP_BF16) {
+    CCHK(prepare_wgrad_bf16());
+    CCHK(prepare_mlp_fwd_bf16(c.W, L.mode));
+    CCHK(prepare_mlp_bwd_bf16(c.W, L.mode));
+  }
   CCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   CCHK(dalloc(&h->d_params, h->nparams));

@@ -19,6 +19,8 @@ hipError_t launch_sample_pdf(const float* w, const float* z, const float* u_rand
 hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float near, float far, int use_ndc,
                            float* rays_o, float* rays_d, float* bounds, hipStream_t s);
 hipError_t launch_to_u8(const float* rgb, int64_t n, uint8_t* out, hipStream_t s);
+size_t composite_bwd_lds_bytes(int S);
+size_t sample_pdf_lds_bytes(int N, int NI, int perturb);
 
 // pack.hip
 hipError_t launch_pack_chunks(const float* params, const ChunkDesc* descs, int n, float* dst, hipStream_t s);
@@ -46,10 +48,18 @@ hipError_t launch_pack_frags_bf16(const float* params, const FragDesc* descs, in
 hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s);
 hipError_t launch_mlp_fwd_bf16(const BfStore* st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                               float* craw, int want_rgb, int nblk, hipStream_t stream);
+                               float* craw, int want_rgb, int nblk, int n_cu, hipStream_t stream);
 
 hipError_t launch_mlp_bwd_bf16(const BfStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
-                               const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, hipStream_t stream);
+                               const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu,
+                               hipStream_t stream);
+// Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised on EVERY
+// device they run on: nerfhip_create calls these with the handle's device current (one process may hold handles on
+// several devices, as the reference does: nerfConfig.device: Array[Device], runNerf.scala:67).
+hipError_t prepare_wgrad_f32();
+hipError_t prepare_wgrad_bf16();
+hipError_t prepare_mlp_fwd_bf16(int W, int mode);
+hipError_t prepare_mlp_bwd_bf16(int W, int mode);
 // wgrad_bf16.hip: one slice of the sample axis of one product, operands in the bf16 store's operand layout
 struct WgradBfItem {
   const uint16_t* A;   // fragment (tile 0, first k-tile of the A rows, s = 0)

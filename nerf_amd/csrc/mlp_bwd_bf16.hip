@@ -219,21 +219,8 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_bwd_bf16_kernel(NetArgs net
 
 template <int WT, int MODE>
 static hipError_t launch_bwd_one(const BfStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
-                                 const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, hipStream_t stream) {
+                                 const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu, hipStream_t stream) {
   const size_t lds = (size_t)kRing * kBlkBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_bf16_kernel<WT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-      n_cu = 256;
-  }
   const int ntiles = (int)((M + kBfTile - 1) / kBfTile);
   const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kBfWaves);
   hipLaunchKernelGGL((mlp_bwd_bf16_kernel<WT, MODE>), grid, block, lds, stream, net, (const char*)stream_w, d_sigma, d_craw,
@@ -243,20 +230,37 @@ static hipError_t launch_bwd_one(const BfStore& st, const NetArgs& net, const vo
 
 template <int WT>
 static hipError_t launch_bwd_mode(const BfStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
-                                  const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, hipStream_t stream) {
+                                  const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu, hipStream_t stream) {
   switch (net.mode) {
-    case 1: return launch_bwd_one<WT, 1>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, stream);
-    case 2: return launch_bwd_one<WT, 2>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, stream);
-    default: return launch_bwd_one<WT, 0>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, stream);
+    case 1: return launch_bwd_one<WT, 1>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, n_cu, stream);
+    case 2: return launch_bwd_one<WT, 2>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, n_cu, stream);
+    default: return launch_bwd_one<WT, 0>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, n_cu, stream);
+  }
+}
+
+// once per device, with that device current (nerfhip_create)
+hipError_t prepare_mlp_bwd_bf16(int W, int mode) {
+  auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+  switch ((W / 32) * 4 + mode) {
+    case 2 * 4 + 0: return set((const void*)mlp_bwd_bf16_kernel<2, 0>);
+    case 2 * 4 + 1: return set((const void*)mlp_bwd_bf16_kernel<2, 1>);
+    case 2 * 4 + 2: return set((const void*)mlp_bwd_bf16_kernel<2, 2>);
+    case 4 * 4 + 0: return set((const void*)mlp_bwd_bf16_kernel<4, 0>);
+    case 4 * 4 + 1: return set((const void*)mlp_bwd_bf16_kernel<4, 1>);
+    case 4 * 4 + 2: return set((const void*)mlp_bwd_bf16_kernel<4, 2>);
+    case 8 * 4 + 0: return set((const void*)mlp_bwd_bf16_kernel<8, 0>);
+    case 8 * 4 + 1: return set((const void*)mlp_bwd_bf16_kernel<8, 1>);
+    case 8 * 4 + 2: return set((const void*)mlp_bwd_bf16_kernel<8, 2>);
+    default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t launch_mlp_bwd_bf16(const BfStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
-                               const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, hipStream_t stream) {
+                               const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu, hipStream_t stream) {
   switch (net.W / 32) {
-    case 2: return launch_bwd_mode<2>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, stream);
-    case 4: return launch_bwd_mode<4>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, stream);
-    case 8: return launch_bwd_mode<8>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, stream);
+    case 2: return launch_bwd_mode<2>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, n_cu, stream);
+    case 4: return launch_bwd_mode<4>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, n_cu, stream);
+    case 8: return launch_bwd_mode<8>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, n_cu, stream);
     default: return hipErrorInvalidValue;
   }
 }

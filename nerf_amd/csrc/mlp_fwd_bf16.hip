@@ -281,23 +281,10 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
 template <int WT, int MODE, bool TRAIN>
 static hipError_t launch_one(const BfStore& st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                              const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                             float* craw, int want_rgb, int nblk, hipStream_t stream) {
+                             float* craw, int want_rgb, int nblk, int n_cu, hipStream_t stream) {
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   const size_t lds = (size_t)kRing * kBlkBytes + ((size_t)net.D * 32 * WT + (HT + 1) * 32 + 32) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-      n_cu = 256;
-  }
   const int ntiles = (int)((M + kBfTile - 1) / kBfTile);
   const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kBfWaves);   // one persistent workgroup per CU
   hipLaunchKernelGGL((mlp_fwd_bf16_kernel<WT, MODE, TRAIN>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
@@ -308,11 +295,33 @@ static hipError_t launch_one(const BfStore& st, const NetArgs& net, const void* 
 template <int WT>
 static hipError_t launch_mode(const BfStore* st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                               const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                              float* craw, int want_rgb, int nblk, hipStream_t stream) {
+                              float* craw, int want_rgb, int nblk, int n_cu, hipStream_t stream) {
   switch (net.mode) {
-    case 1: return st ? launch_one<WT, 1, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream) : launch_one<WT, 1, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
-    case 2: return st ? launch_one<WT, 2, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream) : launch_one<WT, 2, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
-    default: return st ? launch_one<WT, 0, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream) : launch_one<WT, 0, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 1: return st ? launch_one<WT, 1, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream) : launch_one<WT, 1, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream);
+    case 2: return st ? launch_one<WT, 2, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream) : launch_one<WT, 2, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream);
+    default: return st ? launch_one<WT, 0, true>(*st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream) : launch_one<WT, 0, false>(BfStore{}, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream);
+  }
+}
+
+// once per device, with that device current (nerfhip_create): every instantiation may use the whole 160-KiB LDS
+template <int WT, int MODE>
+static hipError_t prepare_fwd_one() {
+  hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+hipError_t prepare_mlp_fwd_bf16(int W, int mode) {
+  switch ((W / 32) * 4 + mode) {
+    case 2 * 4 + 0: return prepare_fwd_one<2, 0>();
+    case 2 * 4 + 1: return prepare_fwd_one<2, 1>();
+    case 2 * 4 + 2: return prepare_fwd_one<2, 2>();
+    case 4 * 4 + 0: return prepare_fwd_one<4, 0>();
+    case 4 * 4 + 1: return prepare_fwd_one<4, 1>();
+    case 4 * 4 + 2: return prepare_fwd_one<4, 2>();
+    case 8 * 4 + 0: return prepare_fwd_one<8, 0>();
+    case 8 * 4 + 1: return prepare_fwd_one<8, 1>();
+    case 8 * 4 + 2: return prepare_fwd_one<8, 2>();
+    default: return hipErrorInvalidValue;
   }
 }
 
@@ -320,11 +329,11 @@ static hipError_t launch_mode(const BfStore* st, const NetArgs& net, const void*
 // (activations also go to the bf16 store)
 hipError_t launch_mlp_fwd_bf16(const BfStore* st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                               float* craw, int want_rgb, int nblk, hipStream_t stream) {
+                               float* craw, int want_rgb, int nblk, int n_cu, hipStream_t stream) {
   switch (net.W / 32) {
-    case 2: return launch_mode<2>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
-    case 4: return launch_mode<4>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
-    case 8: return launch_mode<8>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, stream);
+    case 2: return launch_mode<2>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream);
+    case 4: return launch_mode<4>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream);
+    case 8: return launch_mode<8>(st, net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream);
     default: return hipErrorInvalidValue;
   }
 }

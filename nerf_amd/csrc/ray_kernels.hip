@@ -411,6 +411,13 @@ __global__ void to_u8_kernel(const float* __restrict__ rgb, int64_t n, uint8_t* 
 // ---------------------------------------------------------------------------------------------
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// dynamic LDS of the two per-ray kernels that stage a ray per wave (4 waves per workgroup); nerfhip_create rejects
+// configurations that do not fit 64 KiB
+size_t composite_bwd_lds_bytes(int S) { return (size_t)4 * 3 * ((S + 3) & ~3) * sizeof(float); }
+size_t sample_pdf_lds_bytes(int N, int NI, int perturb) {
+  return (size_t)4 * (2 * ((N + 3) & ~3) + next_pow2(N + NI) + (perturb ? next_pow2(NI) : 0)) * sizeof(float);
+}
+
 hipError_t launch_stratified(const float* bounds, const float* t_rand, int64_t n, int N, int lin_disp, int perturb,
                              uint64_t seed, uint32_t step, float* z, hipStream_t s) {
   const int64_t total = n * N;
@@ -431,7 +438,7 @@ hipError_t launch_composite_bwd(const float* sigma, const float* noise, const fl
                                 const float* d_rgb, int64_t n, int S, float noise_std, int white, uint64_t seed,
                                 uint32_t step, uint32_t stream, float* d_sigma, float* d_craw, hipStream_t s) {
   const int Spad = (S + 3) & ~3;
-  const size_t lds = (size_t)4 * 3 * Spad * sizeof(float);
+  const size_t lds = composite_bwd_lds_bytes(S);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, s, sigma, noise, craw, z,
                      d_rgb, n, S, Spad, noise_std, white, seed, step, stream, d_sigma, d_craw);
@@ -444,7 +451,7 @@ hipError_t launch_sample_pdf(const float* w, const float* z, const float* u_rand
   const int Npad = (N + 3) & ~3;
   const int P = next_pow2(N + NI);
   const int PU = perturb ? next_pow2(NI) : 0;
-  const size_t lds = (size_t)4 * (2 * Npad + P + PU) * sizeof(float);
+  const size_t lds = sample_pdf_lds_bytes(N, NI, perturb);
   if (lds > 64 * 1024 || N < 3) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, s, w, z, u_rand, n, N, NI, Npad,
                      P, PU, perturb, seed, step, cdf, ind, zs, z_fine);

@@ -287,15 +287,15 @@ __global__ __launch_bounds__(256) void ray_sum_kernel(const float* __restrict__ 
   }
 }
 
+// once per device, with that device current (nerfhip_create): allow the kernel its 128 KiB of dynamic LDS
+hipError_t prepare_wgrad_f32() {
+  return hipFuncSetAttribute((const void*)wgrad_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)((size_t)4 * kWgChunkFloats * sizeof(float)));
+}
+
 hipError_t launch_wgrad_f32(const WgradItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s) {
   if (ngroups <= 0) return hipSuccess;
-  const size_t lds = (size_t)4 * kWgChunkFloats * sizeof(float);  // 128 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  const size_t lds = (size_t)4 * kWgChunkFloats * sizeof(float);  // 128 KiB (prepare_wgrad_f32 raised the limit)
   hipLaunchKernelGGL(wgrad_f32_kernel, dim3(ngroups), dim3(256), lds, s, d_items, d_first);
   return hipGetLastError();
 }

@@ -267,15 +267,15 @@ __global__ __launch_bounds__(256) void expand_encdir_bf16_kernel(const float* __
   }
 }
 
+// once per device, with that device current (nerfhip_create)
+hipError_t prepare_wgrad_bf16() {
+  return hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)((size_t)kWbStages * kWbStageBytes));
+}
+
 hipError_t launch_wgrad_bf16(const WgradBfItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s) {
   if (ngroups <= 0) return hipSuccess;
-  const size_t lds = (size_t)kWbStages * kWbStageBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  const size_t lds = (size_t)kWbStages * kWbStageBytes;   // the whole LDS (prepare_wgrad_bf16 raised the limit)
   hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(ngroups), dim3(256), lds, s, d_items, d_first);
   return hipGetLastError();
 }
