@@ -32,7 +32,8 @@ enum {
   NERFHIP_E_INVALID = -1,     /* bad argument / unsupported configuration */
   NERFHIP_E_HIP = -2,         /* a HIP runtime call failed */
   NERFHIP_E_NOMEM = -3,
-  NERFHIP_E_STATE = -4        /* call sequence error (e.g. optimizer_step before backward) */
+  NERFHIP_E_STATE = -4,       /* call sequence error (e.g. optimizer_step before backward) */
+  NERFHIP_E_COMM = -5         /* RCCL could not be loaded or a collective failed */
 };
 
 enum { NERFHIP_F32 = 0, NERFHIP_BF16 = 1 };
@@ -152,6 +153,10 @@ int nerfhip_train_backward_dev(nerfhip_t* h, const float* rays_o, const float* r
  * (replaces DJL's per-parameter reduce inside trainer.step, runNerf.scala:95-106). */
 int nerfhip_grad_buffer(nerfhip_t* h, float** dev_ptr, int64_t* n);
 int nerfhip_get_grads(nerfhip_t* h, float* dst, int64_t n);
+/* Batch.split(devices, false) (runNerf.scala:95) can leave a device without rays when the last batch of an epoch is
+ * smaller than the device count: that replica calls this instead of train_backward -- zero gradient, ready for the
+ * all-reduce and optimizer_step -- so that every rank still takes part in the step's collective. */
+int nerfhip_zero_grads(nerfhip_t* h);
 /* trainer.step() (runNerf.scala:106): Adam(b1 .9, b2 .999, eps 1e-7), lr = lrate * f^t with
  * f = float(0.1^(1/(lrateDecay*1000))) (runNerf.scala:65).  grad_scale multiplies the gradient first
  * (1/world_size for mean-over-devices data parallelism, 1 otherwise). */
@@ -161,6 +166,33 @@ int nerfhip_train_step(nerfhip_t* h, const float* rays_o, const float* rays_d, c
                        const float* viewdir, const float* label, int64_t n, float* loss_out);
 int nerfhip_train_step_dev(nerfhip_t* h, const float* rays_o, const float* rays_d, const float* bounds,
                            const float* viewdir, const float* label, int64_t n, float* loss_out);
+
+/* ---- data-parallel training: the exchange step, native RCCL (no torch, no Python) -------------
+ * replaces: the multi-device branch of the reference's train step -- nerfConfig.device: Array[Device]
+ * (nerfConfig.scala:7), .optDevices(config.device) (runNerf.scala:67), next.split(trainer.getDevices, false) (:95),
+ * per-shard forward/backward (:97-104) and trainer.step() (:106), inside which DJL's parameter server adds the
+ * per-device gradients parameter by parameter through device 0.  Here: ONE in-place ncclAllReduce(sum) of the flat
+ * gradient buffer on RCCL (xGMI inside a node) on the handle's stream, then optimizer_step(1/world) = mean over
+ * devices, so g devices x B rays equal one device running g*B rays.  One handle = one replica on one device.
+ * librccl.so.1 is bound at run time on the first nerfhip_dp_* call (NERFHIP_E_COMM if it cannot be loaded). */
+#define NERFHIP_DP_ID_BYTES 128
+/* rank 0 makes the rendezvous id (ncclGetUniqueId); the HOST carries its 128 bytes to the other ranks */
+int nerfhip_dp_unique_id(uint8_t* id_out /* [NERFHIP_DP_ID_BYTES] */);
+/* one process (or thread) per device: joins the communicator; blocks until all `world` ranks have called */
+int nerfhip_dp_init(nerfhip_t* h, int32_t rank, int32_t world, const uint8_t* id /* [NERFHIP_DP_ID_BYTES] */);
+/* one host thread owning all devices (the reference's shape, runNerf.scala:95-104): handle i becomes rank i of n */
+int nerfhip_dp_init_all(nerfhip_t** handles, int32_t n);
+int nerfhip_dp_world(const nerfhip_t* h, int32_t* rank, int32_t* world);
+/* parameters + Adam moments + update count of `root` to every rank (DJL copies the initialised parameters to every
+ * device in trainer.initialize, runNerf.scala:70).  Collective; synchronises. */
+int nerfhip_dp_broadcast_state(nerfhip_t* h, int32_t root);
+/* in-place all-reduce(sum) of d(loss)/d(params) between train_backward and optimizer_step; asynchronous */
+int nerfhip_dp_allreduce_grads(nerfhip_t* h);
+int nerfhip_dp_allreduce_grads_all(nerfhip_t** handles, int32_t n);   /* single-thread form (grouped) */
+/* train_backward_dev + dp_allreduce_grads + optimizer_step(1/world): one data-parallel iteration of this rank */
+int nerfhip_dp_train_step_dev(nerfhip_t* h, const float* rays_o, const float* rays_d, const float* bounds,
+                              const float* viewdir, const float* label, int64_t n, float* loss_out);
+int nerfhip_dp_destroy(nerfhip_t* h);   /* also done by nerfhip_destroy */
 
 /* ---- single kernels on DEVICE pointers (parity tests and roofline micro-benchmarks) ---------- */
 /* getSample + givePerturb (nerfBlock.scala:47-57,63-64): bounds [n][2] -> z [n][N]. */
@@ -188,6 +220,17 @@ int nerfhip_k_mlp_forward(nerfhip_t* h, int32_t net, const float* rays_o, const 
 int nerfhip_k_gen_rays(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w_host, float near,
                        float far, int32_t ndc, float* rays_o, float* rays_d, float* bounds);
 
+/* The library's own random streams (used when nerfhip_aux leaves t_rand / u_rand / noise_* NULL and the option is on;
+ * the reference draws manager.randomUniform / randomNormal there, nerfBlock.scala:21,55,71).  Counter-based
+ * Philox4x32-10: value = f(seed, stream, step, index), index = flat index of the tensor the stream replaces
+ * (t_rand [n][N], u_rand [n][NI], noise_c [n][N], noise_f [n][S]; NERFHIP_RNG_INIT: flat parameter index, step 0, seed =
+ * the seed given to nerfhip_init_params).  `step` counts the forward passes of the handle: nerfhip_rng_step gives the
+ * step the LAST forward used and the one the next will use.  k_random writes n values of a stream to DEVICE memory
+ * (uniform in (0,1) for PERTURB / PDF, N(0,1) otherwise), so a test can replay a stochastic call with explicit tensors. */
+enum { NERFHIP_RNG_PERTURB = 1, NERFHIP_RNG_PDF = 2, NERFHIP_RNG_NOISE_COARSE = 3, NERFHIP_RNG_NOISE_FINE = 4, NERFHIP_RNG_INIT = 5 };
+int nerfhip_k_random(nerfhip_t* h, int32_t stream, uint64_t seed, uint32_t step, int64_t n, float* out);
+int nerfhip_rng_step(const nerfhip_t* h, uint32_t* last, uint32_t* next);
+
 /* Device time (ms) of the kernels of the last render/train call, by class, measured with HIP events
  * on the handle's stream when profiling is enabled (nerfhip_set_profiling(h,1)). */
 typedef struct nerfhip_prof {
@@ -202,6 +245,8 @@ typedef struct nerfhip_prof {
   double mlp_fwd_flop;   /* algorithmic FLOP of those launches (SURVEY 8d figures) */
   double mlp_bwd_flop;
   double mlp_wgrad_flop;
+  float comm_ms;         /* gradient all-reduce (nerfhip_dp_allreduce_grads) */
+  float reserved2;
 } nerfhip_prof;
 int nerfhip_set_profiling(nerfhip_t* h, int32_t on);
 int nerfhip_get_profile(nerfhip_t* h, nerfhip_prof* out);

@@ -40,7 +40,8 @@ class Prof(C.Structure):
     _fields_ = [("mlp_fwd_ms", C.c_float), ("mlp_bwd_ms", C.c_float), ("mlp_wgrad_ms", C.c_float),
                 ("composite_ms", C.c_float), ("sampling_ms", C.c_float), ("other_ms", C.c_float),
                 ("mlp_fwd_launches", C.c_int32), ("reserved", C.c_int32),
-                ("mlp_fwd_flop", C.c_double), ("mlp_bwd_flop", C.c_double), ("mlp_wgrad_flop", C.c_double)]
+                ("mlp_fwd_flop", C.c_double), ("mlp_bwd_flop", C.c_double), ("mlp_wgrad_flop", C.c_double),
+                ("comm_ms", C.c_float), ("reserved2", C.c_float)]
 
 
 # every symbol include/nerfhip.h declares: (name, restype, argtypes)
@@ -66,15 +67,27 @@ SYMBOLS = {
     "nerfhip_train_backward_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, C.POINTER(Aux)]),
     "nerfhip_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "nerfhip_get_grads": (C.c_int, [_P, _P, _I64]),
+    "nerfhip_zero_grads": (C.c_int, [_P]),
     "nerfhip_optimizer_step": (C.c_int, [_P, _F]),
     "nerfhip_train_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
     "nerfhip_train_step_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "nerfhip_dp_unique_id": (C.c_int, [_P]),
+    "nerfhip_dp_init": (C.c_int, [_P, _I32, _I32, _P]),
+    "nerfhip_dp_init_all": (C.c_int, [C.POINTER(_P), _I32]),
+    "nerfhip_dp_world": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
+    "nerfhip_dp_broadcast_state": (C.c_int, [_P, _I32]),
+    "nerfhip_dp_allreduce_grads": (C.c_int, [_P]),
+    "nerfhip_dp_allreduce_grads_all": (C.c_int, [C.POINTER(_P), _I32]),
+    "nerfhip_dp_train_step_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "nerfhip_dp_destroy": (C.c_int, [_P]),
     "nerfhip_k_stratified": (C.c_int, [_P, _P, _P, _I64, _P]),
     "nerfhip_k_composite_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "nerfhip_k_composite_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "nerfhip_k_sample_pdf": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nerfhip_k_mlp_forward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "nerfhip_k_gen_rays": (C.c_int, [_P, _I32, _I32, _F, _P, _F, _F, _I32, _P, _P, _P]),
+    "nerfhip_k_random": (C.c_int, [_P, _I32, C.c_uint64, C.c_uint32, _I64, _P]),
+    "nerfhip_rng_step": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "nerfhip_set_profiling": (C.c_int, [_P, _I32]),
     "nerfhip_get_profile": (C.c_int, [_P, C.POINTER(Prof)]),
     "nerfhip_version": (C.c_char_p, []),

@@ -221,6 +221,10 @@ class NerfBlock:
         self._chk(self._lib.nerfhip_grad_buffer(self._h, C.byref(p), C.byref(n)), "grad_buffer")
         return p.value, n.value
 
+    def zero_grads(self):
+        """a rank whose shard of the batch is empty contributes zeros to the all-reduce (nerfhip_zero_grads)"""
+        self._chk(self._lib.nerfhip_zero_grads(self._h), "zero_grads")
+
     def optimizer_step(self, grad_scale=1.0):
         """trainer.step() (runNerf.scala:106)."""
         self._chk(self._lib.nerfhip_optimizer_step(self._h, float(grad_scale)), "optimizer_step")
@@ -250,6 +254,38 @@ class NerfBlock:
         rc = self._lib.nerfhip_train_step_dev(self._h, _ptr(rays_o), _ptr(rays_d), _ptr(bounds), _ptr(view_dir),
                                               _ptr(label), n, _ptr(loss_host))
         self._chk(rc, "train_step_dev")
+
+    # ---- data parallelism, native RCCL behind the C ABI (replaces DJL's multi-device trainer.step, runNerf.scala:95-106)
+    @staticmethod
+    def dp_unique_id():
+        """128 rendezvous bytes made by rank 0 (ncclGetUniqueId); the host carries them to the other ranks."""
+        lib = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        _lib.check(lib, None, lib.nerfhip_dp_unique_id(buf), "dp_unique_id")
+        return bytes(buf)
+
+    def dp_init(self, rank, world, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._chk(self._lib.nerfhip_dp_init(self._h, int(rank), int(world), buf), "dp_init")
+
+    def dp_world(self):
+        r, w = C.c_int32(), C.c_int32()
+        self._chk(self._lib.nerfhip_dp_world(self._h, C.byref(r), C.byref(w)), "dp_world")
+        return r.value, w.value
+
+    def dp_broadcast_state(self, root=0):
+        self._chk(self._lib.nerfhip_dp_broadcast_state(self._h, int(root)), "dp_broadcast_state")
+
+    def dp_allreduce_grads(self):
+        self._chk(self._lib.nerfhip_dp_allreduce_grads(self._h), "dp_allreduce_grads")
+
+    def dp_train_step_dev(self, rays_o, rays_d, bounds, view_dir, label, n, loss_host=None):
+        rc = self._lib.nerfhip_dp_train_step_dev(self._h, _ptr(rays_o), _ptr(rays_d), _ptr(bounds), _ptr(view_dir),
+                                                 _ptr(label), n, _ptr(loss_host))
+        self._chk(rc, "dp_train_step_dev")
+
+    def dp_destroy(self):
+        self._chk(self._lib.nerfhip_dp_destroy(self._h), "dp_destroy")
 
     # ---- single kernels on device pointers
     def k_stratified(self, bounds, t_rand, n, z_out):
@@ -281,6 +317,16 @@ class NerfBlock:
                                           _ptr(rays_o), _ptr(rays_d), _ptr(bounds))
         self._chk(rc, "k_gen_rays")
 
+    def k_random(self, stream, seed, step, n, out):
+        """n values of one of the library's Philox streams (1 perturb, 2 pdf: U(0,1); 3/4 raw noise, 5 init: N(0,1))"""
+        self._chk(self._lib.nerfhip_k_random(self._h, int(stream), int(seed), int(step), int(n), _ptr(out)), "k_random")
+
+    def rng_step(self):
+        """(step the last forward pass used, step the next one will use)"""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._chk(self._lib.nerfhip_rng_step(self._h, C.byref(a), C.byref(b)), "rng_step")
+        return a.value, b.value
+
     # ---- profiling
     def set_profiling(self, on=True):
         self._chk(self._lib.nerfhip_set_profiling(self._h, int(on)), "set_profiling")
@@ -288,4 +334,4 @@ class NerfBlock:
     def get_profile(self):
         p = _lib.Prof()
         self._chk(self._lib.nerfhip_get_profile(self._h, C.byref(p)), "get_profile")
-        return {k: getattr(p, k) for k, _ in _lib.Prof._fields_ if k != "reserved"}
+        return {k: getattr(p, k) for k, _ in _lib.Prof._fields_ if not k.startswith("reserved")}

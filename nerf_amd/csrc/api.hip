@@ -53,7 +53,7 @@ struct Net {
   float* d_dcraw = nullptr;    // [max_rays][S][3]
 };
 
-enum ProfClass { P_MLP_FWD = 0, P_MLP_BWD, P_WGRAD, P_COMPOSITE, P_SAMPLING, P_OTHER, P_NCLASS };
+enum ProfClass { P_MLP_FWD = 0, P_MLP_BWD, P_WGRAD, P_COMPOSITE, P_SAMPLING, P_OTHER, P_COMM, P_NCLASS };
 struct ProfRec { int cls; hipEvent_t a, b; };
 }  // namespace
 
@@ -93,6 +93,9 @@ struct nerfhip {
   int64_t items_nr = -1; // ray count the work list in d_items was built for
   double items_flop = 0;
   int n_cu = 256;
+  // data parallelism (dp_rccl.inc): ncclComm_t of this replica, null = single device
+  void* dp_comm = nullptr;
+  int dp_rank = 0, dp_world = 1;
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -474,6 +477,7 @@ int check_handle(nerfhip* h) {
 // include to keep the handle layout in one place)
 #include "train_impl.inc"
 #include "train_bf16.inc"
+#include "dp_rccl.inc"
 
 extern "C" {
 
@@ -613,6 +617,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   if (!h) return;
   hipSetDevice(h->cfg.device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->dp_comm) nerfhip_dp_destroy(h);
   auto fr = [](void* p) { if (p) hipFree(p); };
   fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems);
   for (int i = 0; i < 2; ++i) {
@@ -871,6 +876,22 @@ int nerfhip_k_gen_rays(nerfhip_t* h, int32_t H, int32_t W, float focal, const fl
   return NERFHIP_OK;
 }
 
+int nerfhip_k_random(nerfhip_t* h, int32_t stream, uint64_t seed, uint32_t step, int64_t n, float* out) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!out || n <= 0 || stream < NERFHIP_RNG_PERTURB || stream > NERFHIP_RNG_INIT)
+    return fail(h, NERFHIP_E_INVALID, "k_random: bad argument");
+  const int normal = stream == NERFHIP_RNG_NOISE_COARSE || stream == NERFHIP_RNG_NOISE_FINE || stream == NERFHIP_RNG_INIT;
+  HIPCHK(h, launch_random(seed, (uint32_t)stream, step, n, normal, out, h->stream));
+  return NERFHIP_OK;
+}
+
+int nerfhip_rng_step(const nerfhip_t* h, uint32_t* last, uint32_t* next) {
+  if (!h) return NERFHIP_E_INVALID;
+  if (last) *last = h->last_rng_step;
+  if (next) *next = h->rng_step;
+  return NERFHIP_OK;
+}
+
 // ---- profiling ------------------------------------------------------------------------------------
 int nerfhip_set_profiling(nerfhip_t* h, int32_t on) {
   if (!h) return NERFHIP_E_INVALID;
@@ -891,6 +912,7 @@ int nerfhip_get_profile(nerfhip_t* h, nerfhip_prof* out) {
   }
   out->mlp_fwd_ms = acc[P_MLP_FWD]; out->mlp_bwd_ms = acc[P_MLP_BWD]; out->mlp_wgrad_ms = acc[P_WGRAD];
   out->composite_ms = acc[P_COMPOSITE]; out->sampling_ms = acc[P_SAMPLING]; out->other_ms = acc[P_OTHER];
+  out->comm_ms = acc[P_COMM];
   out->mlp_fwd_launches = h->fwd_launches;
   out->mlp_fwd_flop = h->flop_fwd; out->mlp_bwd_flop = h->flop_bwd; out->mlp_wgrad_flop = h->flop_wgrad;
   return NERFHIP_OK;

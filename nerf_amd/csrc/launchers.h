@@ -19,6 +19,7 @@ hipError_t launch_sample_pdf(const float* w, const float* z, const float* u_rand
 hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float near, float far, int use_ndc,
                            float* rays_o, float* rays_d, float* bounds, hipStream_t s);
 hipError_t launch_to_u8(const float* rgb, int64_t n, uint8_t* out, hipStream_t s);
+hipError_t launch_random(uint64_t seed, uint32_t stream, uint32_t step, int64_t n, int normal, float* out, hipStream_t s);
 size_t composite_bwd_lds_bytes(int S);
 size_t sample_pdf_lds_bytes(int N, int NI, int perturb);
 

@@ -398,6 +398,14 @@ __global__ void gen_rays_kernel(int H, int Wd, float focal, Pose c2w, float near
   bounds[p * 2 + 1] = use_ndc ? nrm : __fmul_rn(nrm, far);
 }
 
+// the library's counter-based random streams, written out (parity tests: the implicit-random branches of the kernels
+// above must equal the explicit-tensor branches fed with these values)
+__global__ void random_kernel(uint64_t seed, uint32_t stream, uint32_t step, int64_t n, int normal, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = normal ? philox_normal(seed, stream, step, (uint64_t)i) : philox_uniform(seed, stream, step, (uint64_t)i);
+}
+
 __global__ void to_u8_kernel(const float* __restrict__ rgb, int64_t n, uint8_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -465,6 +473,12 @@ hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float n
   const int64_t total = (int64_t)H * Wd;
   hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, H, Wd, focal, p, near,
                      far, use_ndc, rays_o, rays_d, bounds);
+  return hipGetLastError();
+}
+
+hipError_t launch_random(uint64_t seed, uint32_t stream, uint32_t step, int64_t n, int normal, float* out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(random_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, stream, step, n, normal, out);
   return hipGetLastError();
 }
 

@@ -57,41 +57,84 @@ def split_batch(n, rank, world):
     return row_block(n, rank, world)
 
 
+def host_staged_all_reduce(group=None):
+    """all-reduce(sum) of a device tensor THROUGH THE HOST: copy down, reduce the host copy, copy back, all ordered on
+    torch's current stream.  For groups whose backend only carries host tensors reliably (gloo); RCCL needs no such
+    staging."""
+    def fn(t):
+        h = t.cpu()                      # synchronises with the current stream: the backward kernels have finished
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)                       # H2D on the current stream, ahead of the optimizer step queued behind it
+    return fn
+
+
 class DataParallel:
     """Wraps an engine with train_backward(...)->losses, grad_view()->1-D tensor, optimizer_step(scale).
 
     `engine` is a nerf_amd.NerfBlock on GPU boxes (see `for_block`); the CPU tests drive the same class with a
     stand-in engine over gloo, so the collective logic is covered without a GPU."""
 
-    def __init__(self, engine, grad_view, group=None, reduce="mean"):
+    def __init__(self, engine, grad_view, group=None, reduce="mean", all_reduce=None):
+        """all_reduce: optional callable(tensor) that sums the tensor over the ranks in place, used instead of
+        dist.all_reduce -- e.g. `host_staged_all_reduce` when the group's backend cannot carry device tensors."""
         if reduce not in ("mean", "sum"):
             raise ValueError("reduce must be 'mean' or 'sum'")
         self.engine = engine
         self.grad_view = grad_view
         self.group = group
         self.reduce = reduce
+        self.all_reduce = all_reduce
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
     @staticmethod
-    def for_block(block, group=None, reduce="mean"):
+    def for_block(block, group=None, reduce="mean", all_reduce=None):
         g = grad_tensor(block)
-        return DataParallel(block, lambda: g, group, reduce)
+        return DataParallel(block, lambda: g, group, reduce, all_reduce)
 
     def train_step(self, backward_fn):
         """backward_fn() runs forward+loss+backward on this rank's shard and returns its losses."""
         losses = backward_fn()
         if self.world > 1:
-            dist.all_reduce(self.grad_view(), op=dist.ReduceOp.SUM, group=self.group)
+            if self.all_reduce is not None:
+                self.all_reduce(self.grad_view())
+            else:
+                dist.all_reduce(self.grad_view(), op=dist.ReduceOp.SUM, group=self.group)
         self.engine.optimizer_step(1.0 / self.world if self.reduce == "mean" else 1.0)
         return losses
 
+    def mean_scalar(self, x, device=None):
+        """mean of a host scalar over the ranks (the loss the run loop prints, runNerf.scala:102)"""
+        if self.world == 1:
+            return x
+        on_dev = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([float(x)], dtype=torch.float64, device=device if on_dev else "cpu")
+        dist.all_reduce(t, group=self.group)
+        return float(t.item()) / self.world
+
+    def _bcast(self, a, src):
+        """broadcast a numpy array through whatever the group's backend can carry: RCCL ("nccl") only moves device
+        tensors, gloo moves host tensors"""
+        if self.world == 1:
+            return a
+        t = torch.from_numpy(a)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=src, group=self.group)
+        return t.cpu().numpy()
+
     def broadcast_params(self, get_params, set_params, src=0):
         """make replicas identical (the reference initialises once and copies to every device)"""
-        p = torch.from_numpy(get_params())
-        if self.world > 1:
-            dist.broadcast(p, src=src, group=self.group)
-        set_params(p.numpy())
+        set_params(self._bcast(get_params(), src))
+
+    def broadcast_state(self, block, src=0):
+        """parameters AND Adam moments / update count of rank `src` to every rank, so that a resume where only one
+        rank loaded the checkpoint cannot diverge"""
+        import numpy as np
+        block.set_params(self._bcast(block.get_params(), src))
+        m, v, step = block.get_opt_state()
+        st = self._bcast(np.array([step], np.int64), src)
+        block.set_opt_state(self._bcast(m, src), self._bcast(v, src), int(st[0]))
 
     def gather_rows(self, local_rows, H):
         """all-gather row blocks of a rendered image (uint8 or float tensor [rows, W, 3]) on every rank"""

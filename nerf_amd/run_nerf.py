@@ -100,7 +100,15 @@ def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None, dp=N
         block = NerfBlock(cfg)
         block.init_params(cfg.seed)
     if dp is not None:
-        dp.broadcast_params(block.get_params, block.set_params)
+        dp.broadcast_state(block)
+    # The device-pointer entry points are asynchronous on the block's stream, and the batches they read are made by
+    # torch ops (the per-epoch gathers of RayBatches): both must be ordered on ONE stream.  The library cannot run on
+    # the legacy default stream, so torch is moved onto an explicit stream shared with the block for the run (the dp
+    # caller has normally done this already; doing it again is harmless) and moved back at the end.
+    import torch
+    from .dp import shared_stream
+    prev_stream = torch.cuda.current_stream(cfg.device)
+    shared_stream(block, device=cfg.device)
     ds = get_data_set(block, cfg, run)
     dirs = {k: os.path.join(run.logDir, k) for k in ("imageLogs", "weightLogs", "videoLogs")}
     if rank == 0:
@@ -126,16 +134,12 @@ def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None, dp=N
             dp.train_step(lambda: block.train_backward_dev(o[i0:i1], d[i0:i1], b[i0:i1], d[i0:i1], lab[i0:i1], i1 - i0, loss))
         else:                                                                          # fewer rays than ranks: contribute zeros
             loss[:] = 0
-            dp.train_step(lambda: dp.grad_view().zero_())
+            dp.train_step(block.zero_grads)
 
     def mean_over_ranks(x):
         if world == 1:
             return x
-        import torch
-        import torch.distributed as dist
-        t = torch.tensor([float(x)], device=f"cuda:{cfg.device}")
-        dist.all_reduce(t, group=dp.group)
-        return np.float32(t.item() / world)                                            # lossValue / splits.length (:102)
+        return np.float32(dp.mean_scalar(x, device=f"cuda:{cfg.device}"))             # lossValue / splits.length (:102)
 
     hier = cfg.useHierarchical
     val_poses = ds.split_poses["val"]
@@ -185,6 +189,9 @@ def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None, dp=N
     finally:
         if logf is not None:
             logf.close()
+        block.synchronize()                      # queued work may still read this epoch's tensors
+        block.set_stream(None)                   # back to the library's own stream
+        torch.cuda.set_stream(prev_stream)
     out["iters"] = idx
     return out
 

@@ -36,6 +36,33 @@ def test_config_struct_matches_header():
     assert _lib.Config.seed.offset == 104
 
 
+def _driver():
+    path = os.path.join(ROOT, "tests", "bin", "c_abi_driver")
+    assert os.path.exists(path), "tests/bin/c_abi_driver is missing: run __graft_entry__.build()"
+    return path
+
+
+def test_c_driver_layout_matches_ctypes():
+    """The plain-C client (tests/c_abi_driver.c, gcc -std=c11 -pedantic against include/nerfhip.h) and the ctypes
+    mirror agree on sizeof / offsetof of every struct of the ABI: what a JNI stub compiled from the header would see."""
+    import subprocess
+    out = subprocess.run([_driver(), "layout"], check=True, capture_output=True, text=True).stdout
+    got = dict(l.rsplit(" ", 1) for l in out.strip().splitlines() if not l.startswith("version"))
+    structs = {"nerfhip_config": _lib.Config, "nerfhip_aux": _lib.Aux, "nerfhip_prof": _lib.Prof}
+    seen = 0
+    for key, val in got.items():
+        kind, name = key.split(".", 1)
+        if kind == "sizeof":
+            assert C.sizeof(structs[name]) == int(val), key
+        elif kind in structs:
+            assert getattr(structs[kind], name).offset == int(val), key
+            seen += 1
+        elif kind == "const":
+            assert {"NERFHIP_MAX_SKIPS": _lib.MAX_SKIPS, "NERFHIP_DP_ID_BYTES": 128, "NERFHIP_E_COMM": -5}[name] == int(val)
+    assert seen == sum(len(s._fields_) for s in structs.values())      # every field of every struct was compared
+    assert "nerfhip" in out.splitlines()[-1]
+
+
 def test_no_gpu_is_a_loud_error():
     import torch
     if torch.cuda.is_available():

@@ -36,18 +36,37 @@ class OracleEngine:
         self.t += 1
         self.o.adam(self.p, self.g.numpy(), self.m, self.v, self.t, scale)
 
+    # the checkpoint interface of NerfBlock that DataParallel.broadcast_state uses
+    def get_params(self):
+        return self.p.copy()
+
+    def set_params(self, p):
+        self.p = np.array(p, np.float32)
+
+    def get_opt_state(self):
+        return self.m.copy(), self.v.copy(), self.t
+
+    def set_opt_state(self, m, v, t):
+        self.m, self.v, self.t = np.array(m, np.float32), np.array(v, np.float32), int(t)
+
 
 def _worker(rank, world, port, reduce, out):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from nerf_amd.dp import DataParallel, split_batch, row_block
+    from nerf_amd.dp import DataParallel, host_staged_all_reduce, split_batch, row_block
     c = H.CONFIGS["small_dir"]
     n = 32
     ro, rd, b, label = H.make_rays(n, 3)
-    eng = OracleEngine(c, H.make_params(c, 1))
-    dp = DataParallel(eng, lambda: eng.g, reduce=reduce)
+    eng = OracleEngine(c, H.make_params(c, 1 + rank))        # replicas differ until rank 0's state is broadcast
+    staged = reduce == "mean_staged"                        # the exchange through an explicit host copy (test_gpu_dp2)
+    dp = DataParallel(eng, lambda: eng.g, reduce="mean" if staged else reduce,
+                      all_reduce=host_staged_all_reduce() if staged else None)
+    eng.m[:] = rank; eng.t = 5 * rank
+    dp.broadcast_state(eng)
+    assert eng.t == 0 and not eng.m.any()
+    assert dp.mean_scalar(float(rank)) == 0.5
     i0, i1 = split_batch(n, rank, world)
     losses = []
     for _ in range(2):
@@ -70,7 +89,7 @@ def _run(reduce):
     return out
 
 
-@pytest.mark.parametrize("reduce", ["mean", "sum"])
+@pytest.mark.parametrize("reduce", ["mean", "sum", "mean_staged"])
 def test_two_rank_training_equals_single_big_batch(reduce):
     out = _run(reduce)
     p0, l0, img0 = out[0]
@@ -85,7 +104,7 @@ def test_two_rank_training_equals_single_big_batch(reduce):
     eng = OracleEngine(c, H.make_params(c, 1))
     for _ in range(2):
         eng.train_backward(ro, rd, b, label)
-        eng.optimizer_step(1.0 if reduce == "mean" else 2.0)   # "sum" of 2 shard-mean grads = 2 x full-batch grad
+        eng.optimizer_step(2.0 if reduce == "sum" else 1.0)   # "sum" of 2 shard-mean grads = 2 x full-batch grad
     np.testing.assert_allclose(p0, eng.p, rtol=0, atol=2e-6)
 
 
