@@ -122,6 +122,17 @@ int nerfhip_render(nerfhip_t* h, const float* rays_o, const float* rays_d, const
                    const float* viewdir, int64_t n, float* rgb, nerfhip_aux* aux);
 int nerfhip_render_dev(nerfhip_t* h, const float* rays_o, const float* rays_d, const float* bounds,
                        const float* viewdir, int64_t n, float* rgb, nerfhip_aux* aux);
+/* nerfhip_render_dev for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same inputs, same rgb, bit for bit; the per-call
+ * intermediates (depths, raw densities, weights, raw colours, direction features) live in a 64-MiB array that is part
+ * of the library's device image (one copy per GPU, held until the process ends) instead of in workspace sized from
+ * max_rays, so n is NOT bounded by max_rays but by nerfhip_render_static_max_rays(h) (64 MiB / bytes per ray of this
+ * configuration; 11 358 rays for the full 64+128 network); larger n -> NERFHIP_E_INVALID.  Calls no hipMalloc / hipFree /
+ * event creation (profiling is off inside it).  Every call on a GPU -- from any handle -- uses that GPU's one array:
+ * calls that overlap on one GPU race; order them on one stream.  Asynchronous like the other _dev entry points. */
+int nerfhip_render_dev_static(nerfhip_t* h, const float* rays_o, const float* rays_d, const float* bounds,
+                              const float* viewdir, int64_t n, float* rgb);
+int64_t nerfhip_render_static_max_rays(const nerfhip_t* h);
 /* + .mul(255).toType(UINT8) (runNerf.scala:194); out [n][3] uint8, clamped to [0,255] then truncated. */
 int nerfhip_render_u8(nerfhip_t* h, const float* rays_o, const float* rays_d, const float* bounds,
                       const float* viewdir, int64_t n, uint8_t* out);

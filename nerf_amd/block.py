@@ -245,6 +245,16 @@ class NerfBlock:
                                           _ptr(rgb_out), None)
         self._chk(rc, "render_dev")
 
+    def render_dev_static(self, rays_o, rays_d, bounds, view_dir, n, rgb_out):
+        """render_dev without any allocation: intermediates in the library's static device scratch (n bounded by
+        render_static_max_rays(), not by maxRays)"""
+        rc = self._lib.nerfhip_render_dev_static(self._h, _ptr(rays_o), _ptr(rays_d), _ptr(bounds), _ptr(view_dir), n,
+                                                 _ptr(rgb_out))
+        self._chk(rc, "render_dev_static")
+
+    def render_static_max_rays(self):
+        return int(self._lib.nerfhip_render_static_max_rays(self._h))
+
     def train_backward_dev(self, rays_o, rays_d, bounds, view_dir, label, n, loss_host=None):
         rc = self._lib.nerfhip_train_backward_dev(self._h, _ptr(rays_o), _ptr(rays_d), _ptr(bounds), _ptr(view_dir),
                                                   _ptr(label), n, _ptr(loss_host), None)

@@ -16,6 +16,14 @@
 
 using namespace nh;
 
+// Scratch of nerfhip_render_dev_static (the entry point that allocates nothing): the per-call intermediates of a
+// render -- depths, raw densities, weights, raw colours, per-ray direction features -- live here instead of in
+// hipMalloc'ed workspace.  One copy per GPU, held until the process ends.  In HOST code this name is only a stand-in
+// for the symbol: its device address is taken once per handle with hipGetSymbolAddress (nerfhip_create) and only that
+// pointer is ever passed to kernels.
+#define NERFHIP_STATIC_SCRATCH_BYTES (64u << 20)
+static __device__ __align__(256) unsigned char scratch[NERFHIP_STATIC_SCRATCH_BYTES];
+
 namespace {
 // text of the last failed nerfhip_create of THIS thread (a failed create has no handle to carry it)
 thread_local std::string g_create_error;
@@ -94,6 +102,7 @@ struct nerfhip {
   double items_flop = 0;
   int n_cu = 256;
   // data parallelism (dp_rccl.inc): ncclComm_t of this replica, null = single device
+  unsigned char* static_scratch = nullptr;   // device address of `scratch` on cfg.device (hipGetSymbolAddress)
   void* dp_comm = nullptr;
   int dp_rank = 0, dp_world = 1;
   // profiling
@@ -367,8 +376,8 @@ int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const floa
 struct DevIn { const float *o, *d, *b, *v; const float *t_rand, *u_rand, *noise_c, *noise_f; };
 
 // nerfBlock.forwardInternal on device buffers; results land in the workspace.
-int forward_dev(nerfhip* h, const DevIn& in, int64_t nr, bool training, bool train_store) {
-  if (nr <= 0 || nr > h->R) return fail(h, NERFHIP_E_INVALID, "n out of range (0 < n <= max_rays)");
+int forward_dev(nerfhip* h, const DevIn& in, int64_t nr, bool training, bool train_store, bool own_bounds = false) {
+  if (nr <= 0 || (!own_bounds && nr > h->R)) return fail(h, NERFHIP_E_INVALID, "n out of range (0 < n <= max_rays)");
   if (!h->packed) { int rc = repack(h); if (rc) return rc; }
   const nerfhip_config& c = h->cfg;
   const int N = h->N, NI = h->NI, S = h->S;
@@ -543,6 +552,7 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
     CCHK(prepare_mlp_fwd_bf16(c.W, L.mode));
     CCHK(prepare_mlp_bwd_bf16(c.W, L.mode));
   }
+  CCHK(hipGetSymbolAddress((void**)&h->static_scratch, HIP_SYMBOL(scratch)));   // this device's copy of the array
   CCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   CCHK(dalloc(&h->d_params, h->nparams));
@@ -728,6 +738,62 @@ int nerfhip_render_dev(nerfhip_t* h, const float* o, const float* d, const float
   rc = copy_out(h, rgb, h->w_rgb_f, n * 3 * sizeof(float), false);
   if (rc) return rc;
   return export_aux(h, aux, n, false, false);
+}
+
+// bytes of static scratch one ray of a render needs (every piece rounded up to 256 B per call, see below)
+static size_t static_floats_per_ray(const nerfhip* h) {
+  const size_t N = h->N, S = h->S;
+  size_t f = 3 + 1 + 1;                                       // rgb, depth, acc
+  f += S * (1 + 1 + 1 + 3);                                   // z, sigma, w, craw of the fine pass
+  if (h->cfg.use_hierarchical) f += N * 3;                    // z, sigma, w of the coarse pass
+  f += (size_t)std::max(32 * h->nets[h->nnets - 1].HT, 12);   // direction features of the fine network
+  return f;
+}
+
+int64_t nerfhip_render_static_max_rays(const nerfhip_t* h) {
+  if (!h) return 0;
+  return (int64_t)((NERFHIP_STATIC_SCRATCH_BYTES - 16 * 256) / (static_floats_per_ray(h) * sizeof(float)));
+}
+
+int nerfhip_render_dev_static(nerfhip_t* h, const float* o, const float* d, const float* b, const float* v, int64_t n,
+                              float* rgb) {
+  int rc = check_handle(h); if (rc) return rc;
+  if (!o || !d || !b || !v || !rgb) return fail(h, NERFHIP_E_INVALID, "render_dev_static: null pointer");
+  if (n <= 0 || n > nerfhip_render_static_max_rays(h))
+    return fail(h, NERFHIP_E_INVALID, "render_dev_static: n exceeds the static scratch (nerfhip_render_static_max_rays: " +
+                                          std::to_string(nerfhip_render_static_max_rays(h)) + " rays for this configuration)");
+  if (h->cfg.dtype == NERFHIP_BF16 && n * (int64_t)h->S >= (int64_t)1 << 31)
+    return fail(h, NERFHIP_E_INVALID, "render_dev_static: rays x samples must be < 2^31 (bf16 kernels)");
+  if (!h->static_scratch) return fail(h, NERFHIP_E_STATE, "render_dev_static: no scratch address for this device");
+  // carve the per-call intermediates out of THIS device's scratch array (pointer from hipGetSymbolAddress); nothing
+  // in it has to start at zero: every element the kernels read is written earlier in the same call
+  unsigned char* p = h->static_scratch;
+  auto take = [&](size_t floats) { float* r = (float*)p; p += (floats * sizeof(float) + 255) / 256 * 256; return r; };
+  const size_t R = (size_t)n, N = h->N, S = h->S;
+  Net& fine = h->nets[h->nnets - 1];
+  struct Saved { float *rgb_f, *depth, *acc, *zc, *sigc, *wc, *zf, *sigf, *wf, *crawf, *dirfeat; bool prof; } sv{
+      h->w_rgb_f, h->w_depth, h->w_acc, h->w_zc, h->w_sigc, h->w_wc, h->w_zf, h->w_sigf, h->w_wf, h->w_crawf, fine.d_dirfeat,
+      h->prof_on};
+  h->w_rgb_f = take(R * 3); h->w_depth = take(R); h->w_acc = take(R);
+  if (h->cfg.use_hierarchical) {
+    h->w_zc = take(R * N); h->w_sigc = take(R * N); h->w_wc = take(R * N);
+    h->w_zf = take(R * S);
+  } else {
+    h->w_zc = take(R * S);   // without a fine pass the coarse depths ARE the fine depths (forward_dev)
+  }
+  h->w_sigf = take(R * S); h->w_wf = take(R * S); h->w_crawf = take(R * S * 3);
+  fine.d_dirfeat = take(R * (size_t)std::max(32 * fine.HT, 12));
+  h->prof_on = false;        // profiling scopes create events: this entry point allocates nothing
+  if ((size_t)(p - h->static_scratch) > NERFHIP_STATIC_SCRATCH_BYTES) rc = fail(h, NERFHIP_E_INVALID, "render_dev_static: scratch overflow");
+  if (!rc) {
+    DevIn in{o, d, b, v, nullptr, nullptr, nullptr, nullptr};
+    rc = forward_dev(h, in, n, false, false, /*own_bounds=*/true);
+  }
+  if (!rc) rc = copy_out(h, rgb, h->w_rgb_f, (size_t)n * 3 * sizeof(float), false);
+  h->w_rgb_f = sv.rgb_f; h->w_depth = sv.depth; h->w_acc = sv.acc; h->w_zc = sv.zc; h->w_sigc = sv.sigc; h->w_wc = sv.wc;
+  h->w_zf = sv.zf; h->w_sigf = sv.sigf; h->w_wf = sv.wf; h->w_crawf = sv.crawf; fine.d_dirfeat = sv.dirfeat;
+  h->prof_on = sv.prof;
+  return rc;
 }
 
 int nerfhip_render(nerfhip_t* h, const float* o, const float* d, const float* b, const float* v, int64_t n, float* rgb,
