@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--no-bf16-render", action="store_true")
     ap.add_argument("--no-bf16-train", action="store_true", help="skip the bf16 training legs (same batch; config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--native-rccl", action="store_true", help="data-parallel exchange through the library's own RCCL "
+                    "entry points (nerfhip_dp_*: no torch in the step) instead of torch.distributed.all_reduce on the "
+                    "gradient buffer; torch.distributed still provides rendezvous, barriers and the max-over-ranks time")
     ap.add_argument("--force-dp", action="store_true", help="take the data-parallel code path (backward, all-reduce, "
                     "optimizer step) even with one rank: rehearsal of the N > 1 loop on a 1-GPU box")
     args = ap.parse_args()
@@ -113,10 +116,31 @@ def main():
     idx = torch.randperm(n_frame, generator=gsel)[:B].cuda()
     t_o, t_d, t_b, t_l = ro[idx].contiguous(), rd[idx].contiguous(), bd[idx].contiguous(), label_full[idx].contiguous()
     grad = grad_tensor(trainer) if dp else None   # zero-copy torch view of the flat gradient buffer
+    native = dp and args.native_rccl
+
+    def native_init(blk):
+        """rank 0's rendezvous id to every rank (carried by the torch group), then ncclCommInitRank inside the library"""
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(NerfBlock.dp_unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(uid, src=0)
+        torch.cuda.synchronize()
+        sys.stdout.flush(); saved_ = os.dup(1); os.dup2(2, 1)      # RCCL's banner must not land on stdout
+        try:
+            blk.dp_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            blk.dp_broadcast_state(0)
+        finally:
+            sys.stdout.flush(); os.dup2(saved_, 1); os.close(saved_)
+
+    if native:
+        native_init(trainer)
 
     def train_step():
         if not dp:
             trainer.train_step_dev(t_o, t_d, t_b, t_d, t_l, B)
+        elif native:
+            trainer.dp_train_step_dev(t_o, t_d, t_b, t_d, t_l, B)    # backward + ncclAllReduce + Adam(1/world), one C call
         else:
             trainer.train_backward_dev(t_o, t_d, t_b, t_d, t_l, B)
             dist.all_reduce(grad)                                  # RCCL: one flat 4.24 MB message
@@ -182,7 +206,7 @@ def main():
     render = {"metric": "rays/sec (render)", "value": round(render_rays_s, 1), "unit": "rays/s",
               "workload": f"{HW}x{HW} frame, {n_frame} rays/GPU/frame", "frames": args.render_frames,
               "ms_per_frame": round(1e3 * dtr / args.render_frames, 3),
-              "samples_per_s": round(render_rays_s * 192, 1),
+              "samples_per_s": round(render_rays_s * 256, 1),      # network evaluations: 64 coarse + 192 fine
               "roofline": {"kernel": "mlp_fwd", "bound": "mfma", "achieved": round(r_ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(r_ach / peak, 4)}}
 
@@ -225,10 +249,14 @@ def main():
         # 1024x1024 forward-facing scene, NDC rays (llff.scala:96-132), 64 + 256 samples per ray
         def timed_train(blk, o_, d_, b_, l_, nsteps):
             g = grad_tensor(blk) if dp else None
+            if native:
+                native_init(blk)
 
             def one():
                 if not dp:
                     blk.train_step_dev(o_, d_, b_, d_, l_, B)
+                elif native:
+                    blk.dp_train_step_dev(o_, d_, b_, d_, l_, B)
                 else:
                     blk.train_backward_dev(o_, d_, b_, d_, l_, B)
                     dist.all_reduce(g)
@@ -382,7 +410,10 @@ def main():
                 "config": {"workload": "full NeRF coarse+fine 64+128 samples/ray, 8x256 MLP, synthetic 400x400 "
                                        "Blender-style scene; train step = fwd+L2+bwd+Adam",
                            "rays_per_gpu_per_step": B, "global_batch": B * world, "samples_per_ray": 192,
-                           "parallelism": f"dp{world}"},
+                           "mlp_evals_per_ray": 256, "parallelism": f"dp{world}",
+                           "exchange": ("native ncclAllReduce (nerfhip_dp_*)" if native else "torch.distributed all_reduce (RCCL)") if dp else "none"},
+                # samples/s counts network evaluations: 64 coarse + 192 fine per ray (the 192 of samples_per_ray are the
+                # compositing samples of the fine pass)
                 "samples_per_s": round(train_rays_s * 256, 1),
                 "roofline": roofline, "render": render, "render_bf16": render_bf16, "train_bf16": train_bf16,
                 "config5_bf16": config5, "render_pose_800": render_pose, "hbm_kernels": hbm_kernels,
