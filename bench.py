@@ -384,13 +384,17 @@ def main():
         ms_sp = timed_kernel(lambda: renderer.k_sample_pdf(wc, zc, None, n_frame, None, None, None, zf))
         nsamp = n_frame * S
 
-        def hbm(ms, nbytes):
+        def hbm(ms, nbytes, kname):
             g = nbytes / ms / 1e6
-            return {"ms": round(ms, 4), "GB/s": round(g, 1), "frac_of_8TB/s": round(g / 8000.0, 3)}
+            r = {"ms": round(ms, 4), "GB/s": round(g, 1), "frac_of_8TB/s": round(g / 8000.0, 3), "algorithmic_bytes": int(nbytes)}
+            r.update(hbm_traffic(kname) if (HW, S) == (400, 192) else {"traffic": None})
+            return r
         hbm_kernels = {"workload": f"{n_frame} rays x {S} samples (resampling: 64 coarse -> 192 fine)",
-                       "composite_fwd": hbm(ms_cf, 24.0 * nsamp + 20.0 * n_frame),
-                       "composite_bwd": hbm(ms_cb, 40.0 * nsamp + 12.0 * n_frame),
-                       "sample_pdf": hbm(ms_sp, n_frame * (8.0 * 64 + 4.0 * 192))}
+                       "timing": "HIP events on the launch stream, 10 launches back to back; rocprofv3 --kernel-trace of "
+                                 "the same shape: profiles/r2_hbm_after_kernel_stats.csv (scripts/hbm_prof.sh)",
+                       "composite_fwd": hbm(ms_cf, 24.0 * nsamp + 20.0 * n_frame, "composite_fwd_k<3>"),
+                       "composite_bwd": hbm(ms_cb, 40.0 * nsamp + 12.0 * n_frame, "composite_bwd_k<3>"),
+                       "sample_pdf": hbm(ms_sp, n_frame * (8.0 * 64 + 4.0 * 192), "sample_pdf_kernel")}
         del sig, crw, zz, w_, dsg, dcr
 
         cpu = None
@@ -442,6 +446,23 @@ def pmc_traffic(dom, dtype):
         return {"traffic": None}
     return {"traffic": round(tot), "traffic_unit": "bytes per train step (all launches of the kernel)",
             "traffic_source": f"profiles/r1_final_{dtype}_pmc_fetchsize.csv, _writesize.csv"}
+
+
+def hbm_traffic(kname):
+    """HBM bytes per launch of one of the per-ray kernels at the 160 000 x 192 shape, from the committed PMC passes
+    (scripts/hbm_prof.sh: FETCH_SIZE and WRITE_SIZE in separate runs, KB, 6 launches each; FETCH_SIZE doubled per
+    the gfx950 correction of MI355X_MICROARCH.md -- for these one-dword-to-four-dword-per-lane loads the doubled figure
+    reproduces the algorithmic read bytes to 2 %)."""
+    import csv
+    tot = 0.0
+    try:
+        for kind, col, mul in (("fetchsize", "FETCH_SIZE", 2.0), ("writesize", "WRITE_SIZE", 1.0)):
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r2_hbm_after_pmc_{kind}.csv"))):
+                if kname in r["kernel"]:
+                    tot += mul * float(r[col]) * 1024.0 / float(r["dispatches"])
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return {"traffic": None}
+    return {"traffic": round(tot), "traffic_source": "profiles/r2_hbm_after_pmc_fetchsize.csv, _writesize.csv"} if tot else {"traffic": None}
 
 
 def cpu_baseline(base, t_o, t_d, t_b, t_l, seconds):

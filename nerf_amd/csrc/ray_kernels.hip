@@ -39,7 +39,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+// sigmoid(x) = 1 / (1 + e^-x) with the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each; the argument
+// scaling x*log2(e) adds |x|*1e-7 relative to e^-x): within 1e-6 relative of the correctly rounded value, against the
+// 1e-5 bar of the composited colour -- and 18 VALU instructions fewer per colour channel than expf + IEEE division,
+// which is what took the compositing kernels from 4.9 to 5.6 TB/s.  Saturates correctly:
+// e^-x = inf -> 0, e^-x = 0 -> 1.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-x))); }
 
 // torch.linspace(0,1,n)[i] (fp32 step; second half evaluated with one rounding)
 __device__ __forceinline__ float linspace01(int i, int n) {
@@ -237,8 +242,225 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Compositing, register form (S <= 64*K, K <= 5: every shape the reference runs -- 64, 64+64, 64+128, 64+256).
+// One wave per ray; lane l owns the K CONSECUTIVE samples K*l .. K*l+K-1, so
+//   * every load/store is one wide access per lane (K = 3: global_load_dwordx3; craw 36 B per lane) and the wave
+//     touches each 128-B line once;
+//   * the cumulative sum is K serial fp64 adds per lane plus ONE wave scan per ray, done with DPP moves
+//     (row_shr 1/2/4/8 inside the 16-lane rows, row_bcast 15/31 across them): 18 VALU, no trip through the LDS
+//     crossbar (the generic kernels below spend most of their time parked on ds_bpermute latencies:
+//     profiles/r2_hbm_before_pmc_sq.csv, SQ_WAIT_ANY 61-66 % of wave cycles);
+//   * T of the sample before a lane's first one is exp(float(exclusive prefix)): no shuffle of T;
+//   * the backward pass needs no LDS at all: T, exp(a) and dw of a lane's samples stay in registers, the suffix sum
+//     is a serial reverse sum per lane plus one scan over mirrored lanes.
+// fp64 partial sums differ from a serial double accumulation by ~1e-16 relative (summation order), far below the
+// fp32 rounding of every element.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {   // lanes that receive nothing read +0.0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ double wave_incl_scan_dpp(double v) {
+  v += dpp_d<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_d<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_d<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_d<0x118, 0xf>(v);   // row_shr:8   -> inclusive scan inside each row of 16
+  v += dpp_d<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_d<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ double wave_shr1(double v) { return dpp_d<0x138, 0xf>(v); }   // lane l <- lane l-1, lane 0 <- 0
+__device__ __forceinline__ float wave_total_dpp(float v) {   // the sum of all lanes, valid in lane 63
+  v += dpp_f<0x111, 0xf>(v); v += dpp_f<0x112, 0xf>(v); v += dpp_f<0x114, 0xf>(v); v += dpp_f<0x118, 0xf>(v);
+  v += dpp_f<0x142, 0xa>(v); v += dpp_f<0x143, 0xc>(v);
+  return v;
+}
+template <int K> struct __attribute__((packed, aligned(4))) PkF { float v[K]; };
+// K consecutive floats of a ray row starting at sample i0 (zero past `limit`): one wide load when all are in range
+template <int K>
+__device__ __forceinline__ void load_run(const float* __restrict__ row, int i0, int limit, float (&out)[K]) {
+  if (i0 + K <= limit) {
+    const PkF<K> p = *reinterpret_cast<const PkF<K>*>(row + i0);
+#pragma unroll
+    for (int j = 0; j < K; ++j) out[j] = p.v[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) out[j] = (i0 + j < limit) ? row[i0 + j] : 0.f;
+  }
+}
+template <int K>
+__device__ __forceinline__ void store_run(float* __restrict__ row, int i0, int limit, const float (&v)[K]) {
+  if (i0 + K <= limit) {
+    PkF<K> p;
+#pragma unroll
+    for (int j = 0; j < K; ++j) p.v[j] = v[j];
+    *reinterpret_cast<PkF<K>*>(row + i0) = p;
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (i0 + j < limit) row[i0 + j] = v[j];
+  }
+}
+
+// a_i = -relu(sigma_i + noise) * (z_{i+1} - z_i) of a lane's K samples (0 for i >= S-1), the effective density,
+// the lane-local inclusive sums in fp64 and the exclusive prefix over the lanes before this one
+template <int K>
+struct LaneScan {
+  float z[K + 1], seff[K], a[K];
+  double cum[K], P;
+};
+template <int K>
+__device__ __forceinline__ void lane_scan(LaneScan<K>& L, const float* __restrict__ sg, const float* __restrict__ zr,
+                                          const float* __restrict__ noise_row, int i0, int S, float noise_std,
+                                          uint64_t seed, uint32_t stream, uint32_t step, int64_t flat0) {
+  load_run<K + 1>(zr, i0, S, L.z);
+  load_run<K>(sg, i0, S - 1, L.seff);
+  if (noise_std > 0.f) {  // addNoise (nerfBlock.scala:21)
+    float nz[K];
+    if (noise_row) load_run<K>(noise_row, i0, S - 1, nz);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (!noise_row) nz[j] = (i0 + j < S - 1) ? philox_normal(seed, stream, step, (uint64_t)(flat0 + j)) : 0.f;
+      L.seff[j] = __fadd_rn(L.seff[j], __fmul_rn(nz[j], noise_std));
+    }
+  }
+  double c = 0.0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    L.a[j] = (i0 + j < S - 1) ? __fmul_rn(-fmaxf(L.seff[j], 0.f), __fsub_rn(L.z[j + 1], L.z[j])) : 0.f;
+    c += (double)L.a[j];
+    L.cum[j] = c;
+  }
+  L.P = wave_shr1(wave_incl_scan_dpp(c));
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void composite_fwd_k(const float* __restrict__ sigma, const float* __restrict__ noise,
+                                                       const float* __restrict__ craw, const float* __restrict__ z,
+                                                       int64_t n, int S, float noise_std, int white, uint64_t seed,
+                                                       uint32_t step, uint32_t stream, float* __restrict__ w,
+                                                       float* __restrict__ rgb, float* __restrict__ depth,
+                                                       float* __restrict__ acc) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n) return;   // wave-uniform
+  const int i0 = lane * K;
+  LaneScan<K> L;
+  lane_scan<K>(L, sigma + ray * S, z + ray * S, noise ? noise + ray * S : nullptr, i0, S, noise_std, seed, stream, step,
+               ray * S + i0);
+  float cr[3 * K];
+  if (craw) load_run<3 * K>(craw + ray * S * 3, 3 * i0, 3 * S, cr);
+  float Tprev = expf((float)L.P);
+  float wv[K], sw = 0.f, sz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int i = i0 + j;
+    const float T = expf((float)(L.P + L.cum[j]));
+    const float alpha = -(__fsub_rn(expf(L.a[j]), 1.0f));
+    const float wi = (i == 0) ? alpha : ((i < S - 1) ? __fmul_rn(Tprev, alpha) : Tprev);
+    Tprev = T;
+    wv[j] = wi;
+    if (i < S) {
+      sw += wi;
+      sz = __fadd_rn(sz, __fmul_rn(wi, L.z[j]));
+      if (craw) {
+        c0 = __fadd_rn(c0, __fmul_rn(wi, sigmoidf_(cr[3 * j + 0])));
+        c1 = __fadd_rn(c1, __fmul_rn(wi, sigmoidf_(cr[3 * j + 1])));
+        c2 = __fadd_rn(c2, __fmul_rn(wi, sigmoidf_(cr[3 * j + 2])));
+      }
+    }
+  }
+  if (w) store_run<K>(w + ray * S, i0, S, wv);
+  sw = wave_total_dpp(sw); sz = wave_total_dpp(sz);
+  if (craw) { c0 = wave_total_dpp(c0); c1 = wave_total_dpp(c1); c2 = wave_total_dpp(c2); }
+  if (lane == 63) {
+    if (rgb && craw) {
+      const float bk = white ? -(__fsub_rn(sw, 1.0f)) : 0.f;  // addBkgd (nerfBlock.scala:24-29)
+      rgb[ray * 3 + 0] = c0 + bk;
+      rgb[ray * 3 + 1] = c1 + bk;
+      rgb[ray * 3 + 2] = c2 + bk;
+    }
+    if (depth) depth[ray] = sz;
+    if (acc) acc[ray] = sw;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void composite_bwd_k(const float* __restrict__ sigma, const float* __restrict__ noise,
+                                                       const float* __restrict__ craw, const float* __restrict__ z,
+                                                       const float* __restrict__ d_rgb, int64_t n, int S,
+                                                       float noise_std, int white, uint64_t seed, uint32_t step,
+                                                       uint32_t stream, float* __restrict__ d_sigma,
+                                                       float* __restrict__ d_craw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n) return;   // wave-uniform
+  const int i0 = lane * K;
+  const float g0 = d_rgb[ray * 3], g1 = d_rgb[ray * 3 + 1], g2 = d_rgb[ray * 3 + 2];
+  const float gsum = g0 + g1 + g2;
+  LaneScan<K> L;
+  lane_scan<K>(L, sigma + ray * S, z + ray * S, noise ? noise + ray * S : nullptr, i0, S, noise_std, seed, stream, step,
+               ray * S + i0);
+  float cr[3 * K];
+  load_run<3 * K>(craw + ray * S * 3, 3 * i0, 3 * S, cr);
+  // forward: T, e = exp(a), dw = d(loss)/d(w) of the lane's samples; d_craw goes out
+  const float Tprev0 = expf((float)L.P);
+  float T[K], e[K], dw[K], dc[3 * K];
+  float Tprev = Tprev0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int i = i0 + j;
+    T[j] = expf((float)(L.P + L.cum[j]));
+    e[j] = expf(L.a[j]);
+    const float alpha = -(__fsub_rn(e[j], 1.0f));
+    const float wi = (i == 0) ? alpha : ((i < S - 1) ? __fmul_rn(Tprev, alpha) : Tprev);
+    Tprev = T[j];
+    const float s0 = sigmoidf_(cr[3 * j]), s1 = sigmoidf_(cr[3 * j + 1]), s2 = sigmoidf_(cr[3 * j + 2]);
+    dc[3 * j + 0] = wi * g0 * s0 * (1.0f - s0);
+    dc[3 * j + 1] = wi * g1 * s1 * (1.0f - s1);
+    dc[3 * j + 2] = wi * g2 * s2 * (1.0f - s2);
+    const float g = g0 * s0 + g1 * s1 + g2 * s2;
+    dw[j] = (i < S) ? (white ? g - gsum : g) : 0.f;
+  }
+  store_run<3 * K>(d_craw + ray * S * 3, 3 * i0, 3 * S, dc);
+  // reverse: da_j = sum_{i>=j} dT_i T_i - dalpha_j e_j ;  d sigma_j = (s_j > 0) ? -dist_j da_j : 0
+  const float dw_next = __shfl_down(dw[0], 1), e_next = __shfl_down(e[0], 1);   // first sample of the next lane
+  double rcum[K], rc = 0.0;
+#pragma unroll
+  for (int j = K - 1; j >= 0; --j) {
+    const int i = i0 + j;
+    const float dwn = (j < K - 1) ? dw[j + 1 < K ? j + 1 : j] : dw_next;
+    const float en = (j < K - 1) ? e[j + 1 < K ? j + 1 : j] : e_next;
+    if (i < S - 1) {
+      const float dT = (i == S - 2) ? dwn : dwn * (1.0f - en);
+      rc += (double)dT * (double)T[j];
+    }
+    rcum[j] = rc;
+  }
+  // exclusive suffix over the lanes after this one: mirror the lanes, prefix-scan, mirror back
+  const double mir = __shfl(rc, 63 - lane);
+  const double Q = __shfl(wave_shr1(wave_incl_scan_dpp(mir)), 63 - lane);
+  float ds[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int i = i0 + j;
+    const float Tm1 = (j == 0) ? Tprev0 : T[j > 0 ? j - 1 : 0];
+    const float dalpha = dw[j] * (i == 0 ? 1.0f : Tm1);
+    const float da = (float)(Q + rcum[j]) + dalpha * (-e[j]);
+    const float dist = __fsub_rn(L.z[j + 1], L.z[j]);
+    ds[j] = (i < S - 1 && L.seff[j] > 0.f) ? (-dist) * da : 0.f;
+  }
+  store_run<K>(d_sigma + ray * S, i0, S, ds);
+}
+
+// ---------------------------------------------------------------------------------------------
 // hierarchical inverse-CDF resampling: one wave per ray, CDF and bins staged in LDS
-// dynamic LDS per wave: cdf[Npad] + bins[Npad] + sortbuf[P] + ubuf[PU]
 // ---------------------------------------------------------------------------------------------
 // every wave sorts its own ray's buffer: LDS operations of one wave execute in order, so a wave-level fence is all
 // the synchronisation a compare-exchange stage needs (no s_barrier: waves may take different paths below)
@@ -262,14 +484,14 @@ __device__ __forceinline__ void bitonic_sort_lds(float* a, int P, int lane) {
   for (int k = 2; k <= P; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) bitonic_stage(a, P, lane, k, j);
 }
-// a[0..P) is bitonic (ascending, then descending): log2(P) stages instead of log2(P)(log2(P)+1)/2
-__device__ __forceinline__ void bitonic_merge_lds(float* a, int P, int lane) {
-  for (int j = P >> 1; j > 0; j >>= 1) bitonic_stage(a, P, lane, P, j);
+__device__ __forceinline__ double wave_last(double v) {   // lane 63's value, through SGPRs
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// LDS per wave: cdf[Npad] | bins[Npad] | zl[Npad] | sb[P] | ub[PU] | mb[Mpad]
 __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict__ w, const float* __restrict__ z,
                                                          const float* __restrict__ u_rand, int64_t n, int N, int NI,
-                                                         int Npad, int P, int PU, int perturb, uint64_t seed,
+                                                         int Npad, int P, int PU, int Mpad, int perturb, uint64_t seed,
                                                          uint32_t step, float* __restrict__ cdf_out,
                                                          int32_t* __restrict__ ind_out, float* __restrict__ zs_out,
                                                          float* __restrict__ z_fine) {
@@ -278,78 +500,109 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
   const int64_t ray_raw = (int64_t)blockIdx.x * 4 + wv;
   const bool live = ray_raw < n;
   const int64_t ray = live ? ray_raw : n - 1;
-  float* cdf = smem + (size_t)wv * (2 * Npad + P + PU);
+  // every wave works in its own slice of LDS: all synchronisation below is wave-level
+  float* cdf = smem + (size_t)wv * (3 * Npad + P + PU + Mpad);
   float* bins = cdf + Npad;
-  float* sb = bins + Npad;
+  float* zl = bins + Npad;
+  float* sb = zl + Npad;
   float* ub = sb + P;
+  float* mb = ub + PU;
   const float* wr = w + ray * N;
   const float* zr = z + ray * N;
   const int nb = N - 1;
-  // weightCum = cumsum(weight[1:-1] + 1e-5)  (nerfBlock.scala:81): fp64 scan, each element rounded to fp32
+  // weightCum = cumsum(weight[1:-1] + 1e-5)  (nerfBlock.scala:81): fp64 scan (DPP), each element rounded to fp32
   double carry = 0.0;
-  for (int base = 0; base < N - 2; base += 64) {
+  bool ordered = true;
+  for (int base = 0; base < N; base += 64) {
     const int k = base + lane;
     const double t = (k < N - 2) ? (double)__fadd_rn(wr[k + 1], 1e-5f) : 0.0;
-    const double run = carry + wave_incl_scan(t, lane);
-    carry = __shfl(run, 63);
+    const double run = carry + wave_incl_scan_dpp(t);
+    carry = wave_last(run);
     if (k < N - 2) cdf[k + 1] = (float)run;
+    if (k < N) {
+      const float z0 = zr[k];
+      zl[k] = z0;
+      if (k < nb) {
+        const float z1 = zr[k + 1];
+        bins[k] = __fmul_rn(__fadd_rn(z1, z0), 0.5f);
+        ordered = ordered && (z0 <= z1);
+      }
+    }
   }
-  for (int k = lane; k < nb; k += 64) bins[k] = __fmul_rn(__fadd_rn(zr[k + 1], zr[k]), 0.5f);
   if (perturb) {  // randomUniform(...).sort(0)  (nerfBlock.scala:71)
     for (int m = lane; m < PU; m += 64)
       ub[m] = m < NI ? (u_rand ? u_rand[ray * NI + m] : philox_uniform(seed, kStreamPdf, step, (uint64_t)(ray * NI + m)))
                      : __builtin_inff();
   }
-  __syncthreads();
+  wave_sync_lds();
   const float sum = cdf[N - 2];
-  __syncthreads();
+  wave_sync_lds();
   for (int k = lane; k < nb; k += 64) cdf[k] = (k == 0) ? 0.f : __fdiv_rn(cdf[k], sum);  // cdf = [0, wc/sum]
+  wave_sync_lds();
   if (perturb) bitonic_sort_lds(ub, PU, lane);
-  __syncthreads();
   if (cdf_out && live)
     for (int k = lane; k < nb; k += 64) cdf_out[ray * nb + k] = cdf[k];
-  for (int m = lane; m < NI; m += 64) {
-    const float u = perturb ? ub[m] : linspace01(m, NI);
-    int lo = 0, hi = nb;  // id = #{cdf <= u}: rank by (stable) double argsort minus m (nerfBlock.scala:89-90)
+  // The merged row sort(concat(samples, z)) (nerfBlock.scala:101) is built by RANK instead of by sorting: a sample s
+  // lands at  m + #{z_i <= s},  a coarse depth z_i at  i + #{s_m < z_i}  -- the positions of a merge of two ascending
+  // rows, i.e. the same multiset in the same (sorted) order as the full sort.  #{z_i <= s} is known to within one
+  // step from the bin the sample fell in (bins are the midpoints of z); #{s_m < z_i} is one binary search over the
+  // samples.  Rows that do not ascend (caller-supplied z through the debug entry point) take the full sort below.
+  float prev_hi = -__builtin_inff();
+  for (int base = 0; base < NI; base += 64) {
+    const int m = base + lane;
+    float s = __builtin_inff();
+    if (m < NI) {
+      const float u = perturb ? ub[m] : linspace01(m, NI);
+      int lo = 0, hi = nb;  // id = #{cdf <= u}: rank by (stable) double argsort minus m (nerfBlock.scala:89-90)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+      }
+      const int id = lo;
+      const int below = max(id - 1, 0);
+      const int above = min(id, nb - 1);
+      const float cb = cdf[below], bb = bins[below];
+      float den = __fsub_rn(cdf[above], cb);
+      if (den < 1e-5f) den = 1.0f;
+      const float t = __fdiv_rn(__fsub_rn(u, cb), den);
+      s = __fadd_rn(bb, __fmul_rn(t, __fsub_rn(bins[above], bb)));
+      sb[m] = s;
+      if (live) {
+        if (ind_out) ind_out[ray * NI + m] = id;
+        if (zs_out) zs_out[ray * NI + m] = s;
+      }
+      int g = min(below + 2, N);   // #{z_i <= s}: z_{below+1} is the only depth inside [bins[below], bins[above]]
+      while (g < N && zl[g] <= s) ++g;
+      while (g > 0 && zl[g - 1] > s) --g;
+      mb[m + g] = s;
+    }
+    // samples ascend? (inside this chunk of 64 and against the chunk before)
+    float left = __shfl_up(s, 1);
+    if (lane == 0) left = prev_hi;
+    ordered = ordered && (m >= NI || left <= s);
+    prev_hi = __shfl(s, 63);
+  }
+  wave_sync_lds();
+  for (int i = lane; i < N; i += 64) {
+    const float zi = zl[i];
+    int lo = 0, hi = NI;   // #{s_m < z_i}
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+      if (sb[mid] < zi) lo = mid + 1; else hi = mid;
     }
-    const int id = lo;
-    const int below = max(id - 1, 0);
-    const int above = min(id, nb - 1);
-    float den = __fsub_rn(cdf[above], cdf[below]);
-    if (den < 1e-5f) den = 1.0f;
-    const float t = __fdiv_rn(__fsub_rn(u, cdf[below]), den);
-    const float s = __fadd_rn(bins[below], __fmul_rn(t, __fsub_rn(bins[above], bins[below])));
-    sb[m] = s;
-    if (live) {
-      if (ind_out) ind_out[ray * NI + m] = id;
-      if (zs_out) zs_out[ray * NI + m] = s;
-    }
+    mb[i + lo] = zi;
   }
-  // sort(concat(samples, z)) (nerfBlock.scala:101).  The samples are non-decreasing in m (u is sorted and every step
-  // of the inverse CDF is monotone under round-to-nearest) and z normally ascends, so the concatenation
-  // [samples | +inf padding | z reversed] is bitonic and ONE merge sorts it -- the same multiset in the same order
-  // as a full sort.  A ray whose z (caller-supplied through the debug entry point) or samples do not ascend takes
-  // the full sort.
-  wave_sync_lds();
-  bool ordered = true;
-  for (int m = lane; m + 1 < NI; m += 64) ordered = ordered && (sb[m] <= sb[m + 1]);
-  for (int i = lane; i + 1 < N; i += 64) ordered = ordered && (zr[i] <= zr[i + 1]);
   ordered = __all(ordered);
   wave_sync_lds();
-  if (ordered) {
-    for (int i = lane; i < P - NI; i += 64) { const int r = P - NI - 1 - i; sb[NI + i] = (r < N) ? zr[r] : __builtin_inff(); }
-    wave_sync_lds();
-    bitonic_merge_lds(sb, P, lane);
-  } else {
-    for (int i = lane; i < P - NI; i += 64) sb[NI + i] = (i < N) ? zr[i] : __builtin_inff();
+  const float* src = mb;
+  if (!ordered) {
+    for (int i = lane; i < P - NI; i += 64) sb[NI + i] = (i < N) ? zl[i] : __builtin_inff();
     wave_sync_lds();
     bitonic_sort_lds(sb, P, lane);
+    src = sb;
   }
   if (live)
-    for (int i = lane; i < N + NI; i += 64) z_fine[ray * (N + NI) + i] = sb[i];
+    for (int i = lane; i < N + NI; i += 64) z_fine[ray * (N + NI) + i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,7 +676,7 @@ static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 // configurations that do not fit 64 KiB
 size_t composite_bwd_lds_bytes(int S) { return (size_t)4 * 3 * ((S + 3) & ~3) * sizeof(float); }
 size_t sample_pdf_lds_bytes(int N, int NI, int perturb) {
-  return (size_t)4 * (2 * ((N + 3) & ~3) + next_pow2(N + NI) + (perturb ? next_pow2(NI) : 0)) * sizeof(float);
+  return (size_t)4 * (3 * ((N + 3) & ~3) + next_pow2(N + NI) + (perturb ? next_pow2(NI) : 0) + ((N + NI + 3) & ~3)) * sizeof(float);
 }
 
 hipError_t launch_stratified(const float* bounds, const float* t_rand, int64_t n, int N, int lin_disp, int perturb,
@@ -437,14 +690,38 @@ hipError_t launch_stratified(const float* bounds, const float* t_rand, int64_t n
 hipError_t launch_composite_fwd(const float* sigma, const float* noise, const float* craw, const float* z, int64_t n,
                                 int S, float noise_std, int white, uint64_t seed, uint32_t step, uint32_t stream,
                                 float* w, float* rgb, float* depth, float* acc, hipStream_t s) {
-  hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, sigma, noise, craw, z, n, S,
-                     noise_std, white, seed, step, stream, w, rgb, depth, acc);
+  const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define NH_FWD_K(KK) hipLaunchKernelGGL(composite_fwd_k<KK>, grid, block, 0, s, sigma, noise, craw, z, n, S, noise_std, white, \
+                                        seed, step, stream, w, rgb, depth, acc)
+  switch ((S + 63) / 64) {   // samples per lane of the register form; longer rays take the generic chunked kernel
+    case 1: NH_FWD_K(1); break;
+    case 2: NH_FWD_K(2); break;
+    case 3: NH_FWD_K(3); break;
+    case 4: NH_FWD_K(4); break;
+    case 5: NH_FWD_K(5); break;
+    default:
+      hipLaunchKernelGGL(composite_fwd_kernel, grid, block, 0, s, sigma, noise, craw, z, n, S, noise_std, white, seed, step,
+                         stream, w, rgb, depth, acc);
+  }
+#undef NH_FWD_K
   return hipGetLastError();
 }
 
 hipError_t launch_composite_bwd(const float* sigma, const float* noise, const float* craw, const float* z,
                                 const float* d_rgb, int64_t n, int S, float noise_std, int white, uint64_t seed,
                                 uint32_t step, uint32_t stream, float* d_sigma, float* d_craw, hipStream_t s) {
+  const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define NH_BWD_K(KK) hipLaunchKernelGGL(composite_bwd_k<KK>, grid, block, 0, s, sigma, noise, craw, z, d_rgb, n, S, noise_std, \
+                                        white, seed, step, stream, d_sigma, d_craw)
+  switch ((S + 63) / 64) {
+    case 1: NH_BWD_K(1); return hipGetLastError();
+    case 2: NH_BWD_K(2); return hipGetLastError();
+    case 3: NH_BWD_K(3); return hipGetLastError();
+    case 4: NH_BWD_K(4); return hipGetLastError();
+    case 5: NH_BWD_K(5); return hipGetLastError();
+    default: break;
+  }
+#undef NH_BWD_K
   const int Spad = (S + 3) & ~3;
   const size_t lds = composite_bwd_lds_bytes(S);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
@@ -462,7 +739,7 @@ hipError_t launch_sample_pdf(const float* w, const float* z, const float* u_rand
   const size_t lds = sample_pdf_lds_bytes(N, NI, perturb);
   if (lds > 64 * 1024 || N < 3) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, s, w, z, u_rand, n, N, NI, Npad,
-                     P, PU, perturb, seed, step, cdf, ind, zs, z_fine);
+                     P, PU, (N + NI + 3) & ~3, perturb, seed, step, cdf, ind, zs, z_fine);
   return hipGetLastError();
 }
 

@@ -115,7 +115,7 @@ def test_sample_pdf_golden(G):
         blk.close()
 
 
-@pytest.mark.parametrize("S,white", [(64, True), (192, True), (320, False), (17, True)])
+@pytest.mark.parametrize("S,white", [(64, True), (192, True), (320, False), (17, True), (128, False), (250, True), (400, True), (2, True)])
 def test_composite_fwd(G, S, white):
     """fp32 compositing: weights / rgb / depth / acc within 1e-5 relative of the oracle (north_star)."""
     c = H.cfg(whiteBkgd=white)

@@ -25,7 +25,7 @@ def G():
     return gpu_util
 
 
-@pytest.mark.parametrize("S,white", [(64, True), (192, True), (320, False), (17, False)])
+@pytest.mark.parametrize("S,white", [(64, True), (192, True), (320, False), (17, False), (128, True), (250, False), (400, False), (2, True)])
 def test_composite_bwd(G, S, white):
     """reverse-mode compositing vs oracle: 1e-4 relative to the largest gradient of the ray batch."""
     c = H.cfg(whiteBkgd=white)
