@@ -592,6 +592,99 @@ void orc_mlp_forward(const orc_config* c, const float* net_params, int32_t is_co
   net_forward(c, L, net_params, want_rgb, B, S, rays_o, rays_d, viewdir, z, sigma, craw, nullptr);
 }
 
+// The same network evaluated in the SUMMATION ORDER of the fp32 MFMA kernels (nerf_amd/csrc/mlp_fwd.hip,
+// mlp_common.cuh:9-17), so that a test can hold the kernel to (near-)bitwise agreement instead of the loose bar a
+// different GEMM order forces: every Linear output is  acc = bias;  for kt, q, j, h: k = 32 kt + 8 q + 4 h + j:
+// acc = fmaf(w[k], x[k], acc)  (v_mfma_f32_32x32x2_f32 == an fmaf chain over its two k values, bitwise); the density
+// row and the colour output rows are two chains, one per lane half h (k = 32 t + 8 q + 4 h + j), added at the end;
+// the view-direction branch is un-fused mul/add in natural order plus bf (pack.hip: dir_branch_kernel).  Does not
+// follow the reference more closely than net_forward -- it follows the KERNEL; with posL = dirL = 0 (no sin/cos) the
+// two must agree bit for bit.
+static float korder_dot(const float* w, const float* x, int K, float acc) {
+  for (int kt = 0; kt * 32 < K; ++kt)
+    for (int q = 0; q < 4; ++q)
+      for (int j = 0; j < 4; ++j)
+        for (int h = 0; h < 2; ++h) {
+          const int k = 32 * kt + 8 * q + 4 * h + j;
+          if (k < K) acc = fmaf(w[k], x[k], acc);
+        }
+  return acc;
+}
+static float khalf_dot(const float* w, const float* x, int K, int h) {   // one lane half of a VALU dot product
+  float part = 0.f;
+  for (int t = 0; t * 32 < K; ++t)
+    for (int q = 0; q < 4; ++q)
+      for (int j = 0; j < 4; ++j) {
+        const int k = 32 * t + 8 * q + 4 * h + j;
+        if (k < K) part = fmaf(x[k], w[k], part);
+      }
+  return part;
+}
+
+void orc_mlp_forward_korder(const orc_config* c, const float* P, int32_t want_rgb, int64_t B, int32_t S,
+                            const float* rays_o, const float* rays_d, const float* viewdir, const float* z,
+                            float* sigma, float* craw) {
+  const NetLayout L = make_layout(c);
+  const int E = L.E, W = L.W, D = L.D, H2 = L.H2, Ed = L.Ed;
+  const int64_t M = B * S;
+#pragma omp parallel for schedule(static)
+  for (int64_t m = 0; m < M; ++m) {
+    const int64_t b = m / S;
+    float pos[3];
+    for (int k = 0; k < 3; ++k) pos[k] = rays_o[b * 3 + k] + rays_d[b * 3 + k] * z[m];
+    std::vector<float> enc(E), cur(W + E), nxt(W + E);
+    position_code_row(pos, c->pos_l, enc.data());
+    std::copy(enc.begin(), enc.end(), cur.begin());
+    int cur_w = E;
+    for (int l = 0; l < D; ++l) {
+      const float* Wm = P + L.w_off[l];
+      for (int i = 0; i < W; ++i) {
+        // activations first (W is a multiple of 32, so the concatenated index walks the kernel's chunks in order),
+        // then the two encoding chunks of a skip layer
+        const float v = korder_dot(Wm + (int64_t)i * cur_w, cur.data(), cur_w, P[L.b_off[l] + i]);
+        nxt[i] = v > 0.f ? v : 0.f;
+      }
+      cur_w = W;
+      if (is_skip(c, l)) { std::copy(enc.begin(), enc.end(), nxt.begin() + W); cur_w = W + E; }
+      std::swap(cur, nxt);
+    }
+    // (the kernels support skips in [0, D-2] only, so cur_w == W here)
+    if ((m % S) == S - 1) sigma[m] = 0.f;
+    else sigma[m] = (khalf_dot(P + L.ws_off, cur.data(), W, 0) + khalf_dot(P + L.ws_off, cur.data(), W, 1)) + P[L.bs_off];
+    if (!want_rgb || !craw) continue;
+    if (L.mode == 1) {
+      std::vector<float> encd(Ed), hc(H2);
+      position_code_row(viewdir + b * 3, c->dir_l, encd.data());
+      for (int j = 0; j < H2; ++j) {
+        float dv = P[L.bd_off + j];
+        for (int e = 0; e < Ed; ++e) dv = dv + encd[e] * P[L.wd_off + (int64_t)j * Ed + e];   // un-fused (-ffp-contract=off)
+        dv = dv + P[L.bf_off + j];
+        const float v = korder_dot(P + L.wf_off + (int64_t)j * W, cur.data(), W, dv);
+        hc[j] = v > 0.f ? v : 0.f;
+      }
+      for (int k = 0; k < 3; ++k) {
+        const float* w3 = P + L.w3_off + (int64_t)k * H2;
+        craw[m * 3 + k] = (khalf_dot(w3, hc.data(), H2, 0) + P[L.b3_off + k]) + khalf_dot(w3, hc.data(), H2, 1);
+      }
+    } else if (L.mode == 2) {
+      float Y[9], q[27];
+      sh2_row(viewdir + b * 3, Y);
+      for (int r = 0; r < 27; ++r) q[r] = korder_dot(P + L.wf_off + (int64_t)r * W, cur.data(), W, P[L.bf_off + r]);
+      for (int k = 0; k < 3; ++k) {
+        float part[2] = {0.f, 0.f};
+        for (int h = 0; h < 2; ++h)
+          for (int r = 0; r < 16; ++r) {   // accumulator register order of tile 0: row = (r&3) + 8 (r>>2) + 4 h
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < 27 && row % 3 == k) part[h] = part[h] + q[row] * Y[row / 3];
+          }
+        craw[m * 3 + k] = part[0] + part[1];
+      }
+    } else {
+      for (int k = 0; k < 3; ++k) craw[m * 3 + k] = korder_dot(P + L.wf_off + (int64_t)k * W, cur.data(), W, P[L.bf_off + k]);
+    }
+  }
+}
+
 }  // extern "C"
 
 namespace {

@@ -180,6 +180,17 @@ class Oracle:
                                _f(sigma), _f(craw))
         return sigma, craw
 
+    def mlp_forward_korder(self, net_params, want_rgb, rays_o, rays_d, viewdir, z):
+        """the network in the summation order of the fp32 MFMA kernels (orc_mlp_forward_korder)"""
+        z = _arr(z)
+        B, S = z.shape
+        net_params = _arr(net_params); rays_o = _arr(rays_o, (B, 3)); rays_d = _arr(rays_d, (B, 3))
+        viewdir = _arr(viewdir, (B, 3))
+        sigma = np.zeros((B, S), np.float32); craw = np.zeros((B, S, 3), np.float32)
+        self.L.orc_mlp_forward_korder(C.byref(self.c), _f(net_params), C.c_int32(int(want_rgb)), C.c_int64(B),
+                                      C.c_int32(S), _f(rays_o), _f(rays_d), _f(viewdir), _f(z), _f(sigma), _f(craw))
+        return sigma, craw
+
     def _io(self, B, rand):
         N, NI, S = self.N, self.NI, self.S
         out = {
