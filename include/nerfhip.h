@@ -36,7 +36,11 @@ enum {
   NERFHIP_E_COMM = -5         /* RCCL could not be loaded or a collective failed */
 };
 
-enum { NERFHIP_F32 = 0, NERFHIP_BF16 = 1 };
+/* MFMA operand type of the MLP kernels.  F32: v_mfma_f32_32x32x2_f32 everywhere (the parity mode).  BF16: bf16 operands,
+ * fp32 accumulation (renders within 1e-2 abs).  F16X3: RENDER with split-f16 operands (x = hi + lo/2048, three f16
+ * MFMAs per product, fp32 accumulation): fp32-grade results -- held to the same parity tests and tolerances as F32 --
+ * at about 3x the F32 render rate; training calls on such a handle run the F32 kernels. */
+enum { NERFHIP_F32 = 0, NERFHIP_BF16 = 1, NERFHIP_F16X3 = 2 };
 
 /* Mirrors the arithmetic-relevant fields of nerf/nerfConfig.scala:20-43 (same meaning, same order),
  * followed by build-side extensions. */

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnerfhip.so")
 
 MAX_SKIPS = 8
-F32, BF16 = 0, 1
+F32, BF16, F16X3 = 0, 1, 2
 
 
 class Config(C.Structure):

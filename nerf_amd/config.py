@@ -29,7 +29,7 @@ class NerfConfig:
     lrateDecay: int = 250            # :43
     # ---- build extensions
     device: int = 0                  # nerfConfig.device (:7) -> HIP ordinal of THIS process' GPU
-    dtype: str = "f32"               # "f32" | "bf16": MFMA operand type of the MLP
+    dtype: str = "f32"               # "f32" | "bf16" | "f16x3" (fp32-grade split-f16 render, fp32 training)
     seed: int = 0
     maxRays: int = 4096              # workspace is sized once for this many rays per call
 
@@ -59,7 +59,7 @@ class NerfConfig:
         c.white_bkgd, c.lin_disp, c.perturb = int(self.whiteBkgd), int(self.linDisp), int(self.perturb)
         c.lrate, c.lrate_decay = float(self.lrate), int(self.lrateDecay)
         c.device = self.device
-        c.dtype = {"f32": _lib.F32, "bf16": _lib.BF16}[self.dtype]
+        c.dtype = {"f32": _lib.F32, "bf16": _lib.BF16, "f16x3": _lib.F16X3}[self.dtype]
         c.seed = self.seed
         c.max_rays = self.maxRays
         return c

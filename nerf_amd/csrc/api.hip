@@ -52,6 +52,12 @@ struct Net {
   std::vector<FragDesc> bf_bwd;                 // backward stream (transposed matrices)
   FragDesc* d_bf_bwd_desc = nullptr;
   void* d_bf_bwd = nullptr;
+  // split-f16 path (cfg.dtype == NERFHIP_F16X3): forward streams of (hi, lo) fragment pairs (f16x3_common.cuh)
+  std::vector<FragDesc> x3_full, x3_sigma;
+  FragDesc* d_x3_full_desc = nullptr;
+  FragDesc* d_x3_sigma_desc = nullptr;
+  void* d_x3_full = nullptr;
+  void* d_x3_sigma = nullptr;
   BfStore bst{};                                // bf16 training store (allocated on first training call)
   float* d_dirfeat = nullptr;  // [max_rays][max(32*HT, 12)]
   float* d_encdirT = nullptr;  // training, mode 1: [32][Bpad]
@@ -199,12 +205,13 @@ void build_chunks(Net& n) {
 }
 
 // bf16 forward streams: fragments in consumption order, every layer part padded to a whole 32-fragment block
-void build_bf16_streams(Net& n) {
+// (pad_to = 32); the split-f16 kernel stores a (hi, lo) PAIR per descriptor, so its parts are padded to 16
+void build_fwd_streams(const Net& n, int pad_to, std::vector<FragDesc>& out_full, std::vector<FragDesc>& out_sigma) {
   const NetLayout& L = n.L;
   const int W = L.W, WT = n.WT;
   const int HT = L.mode == 1 ? std::max(1, WT / 2) : 1;   // colour-hidden tiles (kernel template)
-  auto pad = [](std::vector<FragDesc>& v) {
-    while (v.size() % 32) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 0});
+  auto pad = [pad_to](std::vector<FragDesc>& v) {
+    while (v.size() % pad_to) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 0});
   };
   auto ksteps = [&](std::vector<FragDesc>& v, int64_t off, int ld, int row0, int nrows, int col_base, int kfeat) {
     for (int kt = 0; kt * 32 < kfeat; ++kt)
@@ -227,21 +234,31 @@ void build_bf16_streams(Net& n) {
       pad(v);
     }
   };
-  n.bf_full.clear(); n.bf_sigma.clear();
-  trunk(n.bf_full);
-  for (int ot = 0; ot < HT; ++ot) ksteps(n.bf_full, L.wf_off, W, 32 * ot, L.head_rows, 0, W);
-  ksteps(n.bf_full, L.ws_off, W, 0, 1, 0, W);   // density tile: row 0
-  pad(n.bf_full);
+  out_full.clear(); out_sigma.clear();
+  trunk(out_full);
+  for (int ot = 0; ot < HT; ++ot) ksteps(out_full, L.wf_off, W, 32 * ot, L.head_rows, 0, W);
+  ksteps(out_full, L.ws_off, W, 0, 1, 0, W);   // density tile: row 0
+  pad(out_full);
   if (L.mode == 1) {
     for (int kt = 0; kt < HT; ++kt)
       for (int s = 0; s < 2; ++s)
-        n.bf_full.push_back(FragDesc{L.wc_off, L.H2, 0, 3, 32 * kt, std::max(0, std::min(32, L.H2 - 32 * kt)), s, 0});
-    pad(n.bf_full);
+        out_full.push_back(FragDesc{L.wc_off, L.H2, 0, 3, 32 * kt, std::max(0, std::min(32, L.H2 - 32 * kt)), s, 0});
+    pad(out_full);
   }
-  trunk(n.bf_sigma);
-  ksteps(n.bf_sigma, L.ws_off, W, 0, 1, 0, W);
-  pad(n.bf_sigma);
+  trunk(out_sigma);
+  ksteps(out_sigma, L.ws_off, W, 0, 1, 0, W);
+  pad(out_sigma);
 
+}
+
+void build_bf16_streams(Net& n) {
+  const NetLayout& L = n.L;
+  const int W = L.W, WT = n.WT;
+  const int HT = L.mode == 1 ? std::max(1, WT / 2) : 1;
+  auto pad = [](std::vector<FragDesc>& v) {
+    while (v.size() % 32) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 0});
+  };
+  build_fwd_streams(n, 32, n.bf_full, n.bf_sigma);
   // backward stream (mlp_bwd_bf16.hip): element (row = input feature i, k = output feature) = M[k][i]
   auto tfrag = [&](int64_t off, int ld, int row0, int nrows, int col0, int kvalid, int sidx) {
     n.bf_bwd.push_back(FragDesc{off, ld, row0, nrows, col0, std::max(0, std::min(32, kvalid)), sidx, 1});
@@ -331,6 +348,11 @@ int repack(nerfhip* h) {
       HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));
       HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
       HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
+      if (h->cfg.dtype == NERFHIP_F16X3) {   // + the render kernel's pair streams (training stays on the fp32 kernels)
+        HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->stream));
+        HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, h->stream));
+        HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, h->stream));
+      }
     } else {
       HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_full_desc, (int)n.bf_full.size(), n.d_bf_full, h->stream));
       HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_sigma_desc, (int)n.bf_sigma.size(), n.d_bf_sigma, h->stream));
@@ -356,7 +378,11 @@ int dir_features(nerfhip* h, Net& n, const float* viewdir, int64_t nr, bool trai
 int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const float* d, const float* z, int64_t nr, int S,
                 float* sigma, float* craw, bool want_rgb) {
   Scope sc(h, P_MLP_FWD);
-  if (h->cfg.dtype == NERFHIP_BF16) {
+  if (h->cfg.dtype == NERFHIP_F16X3 && !train_store) {
+    HIPCHK(h, launch_mlp_fwd_f16x3(net_args(h, n), want_rgb ? n.d_x3_full : n.d_x3_sigma, n.d_bvec, o, d, z, n.d_dirfeat, nr * S, S,
+                                   sigma, craw, want_rgb ? 1 : 0, (int)((want_rgb ? n.x3_full.size() : n.x3_sigma.size()) / 16),
+                                   h->n_cu, h->stream));
+  } else if (h->cfg.dtype == NERFHIP_BF16) {
     BfStore bst = n.bst;
     bst.Mpad = (nr * S + 255) / 256 * 256;
     HIPCHK(h, launch_mlp_fwd_bf16(train_store ? &bst : nullptr, net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z, n.d_dirfeat,
@@ -490,7 +516,7 @@ int check_handle(nerfhip* h) {
 
 extern "C" {
 
-const char* nerfhip_version(void) { return "nerfhip 0.1 (gfx950, fp32 and bf16 MFMA)"; }
+const char* nerfhip_version(void) { return "nerfhip 0.2 (gfx950; fp32, bf16 and split-f16 MFMA)"; }
 
 const char* nerfhip_last_error(const nerfhip_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -510,11 +536,11 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
   if (c.use_hierarchical && (c.n_importance < 1 || c.n_samples + c.n_importance > 2048))
     return bad("NImportance must be >= 1 and NSamples+NImportance <= 2048");
   if (c.max_rays < 1) return bad("max_rays must be >= 1");
-  if (c.dtype != NERFHIP_F32 && c.dtype != NERFHIP_BF16) return bad("unknown dtype");
-  if (c.dtype == NERFHIP_BF16) {   // limits of the bf16 kernels (tile indices are 32-bit; W/32 in {2,4,8})
-    if (c.W == 32) return bad("dtype bf16 needs W = 64, 128 or 256");
+  if (c.dtype != NERFHIP_F32 && c.dtype != NERFHIP_BF16 && c.dtype != NERFHIP_F16X3) return bad("unknown dtype");
+  if (c.dtype == NERFHIP_BF16 || c.dtype == NERFHIP_F16X3) {   // limits of the 16-bit-operand kernels (tile indices are 32-bit; W/32 in {2,4,8})
+    if (c.W == 32) return bad("dtype bf16 / f16x3 needs W = 64, 128 or 256");
     const long long smax = c.use_hierarchical ? c.n_samples + c.n_importance : c.n_samples;
-    if ((long long)c.max_rays * smax >= (1LL << 31)) return bad("dtype bf16: max_rays x samples per ray must be < 2^31");
+    if ((long long)c.max_rays * smax >= (1LL << 31)) return bad("dtype bf16 / f16x3: max_rays x samples per ray must be < 2^31");
   }
   if (c.lrate_decay <= 0) return bad("lrateDecay must be > 0");
   { // per-ray kernels stage one ray per wave in at most 64 KiB of LDS per 4-wave workgroup (ray_kernels.hip)
@@ -552,6 +578,7 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
     CCHK(prepare_mlp_fwd_bf16(c.W, L.mode));
     CCHK(prepare_mlp_bwd_bf16(c.W, L.mode));
   }
+  if (c.dtype == NERFHIP_F16X3) CCHK(prepare_mlp_fwd_f16x3(c.W, L.mode));
   CCHK(hipGetSymbolAddress((void**)&h->static_scratch, HIP_SYMBOL(scratch)));   // this device's copy of the array
   CCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
@@ -604,6 +631,19 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
       CCHK(hipMalloc(&n.d_bf_bwd, (n.bf_bwd.size() + padf) * 1024));
       CCHK(hipMemsetAsync(n.d_bf_bwd, 0, (n.bf_bwd.size() + padf) * 1024, h->stream));
     }
+    if (c.dtype == NERFHIP_F16X3) {
+      build_fwd_streams(n, 16, n.x3_full, n.x3_sigma);
+      const size_t padf = 4 * 32;   // the LDS ring requests up to 3 blocks (of 32 fragments) past the end
+      CCHK(dalloc(&n.d_x3_full_desc, n.x3_full.size()));
+      CCHK(dalloc(&n.d_x3_sigma_desc, n.x3_sigma.size()));
+      CCHK(hipMemcpy(n.d_x3_full_desc, n.x3_full.data(), n.x3_full.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMemcpy(n.d_x3_sigma_desc, n.x3_sigma.data(), n.x3_sigma.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMalloc(&n.d_x3_full, (2 * n.x3_full.size() + padf) * 1024));
+      CCHK(hipMalloc(&n.d_x3_sigma, (2 * n.x3_sigma.size() + padf) * 1024));
+      CCHK(hipMemsetAsync(n.d_x3_full, 0, (2 * n.x3_full.size() + padf) * 1024, h->stream));
+      CCHK(hipMemsetAsync(n.d_x3_sigma, 0, (2 * n.x3_sigma.size() + padf) * 1024, h->stream));
+      CCHK(dalloc(&n.d_bvec, (size_t)L.D * L.W + 5 * 32 + 32));
+    }
     CCHK(dalloc(&n.d_dirfeat, (size_t)h->R * std::max(32 * n.HT, 12)));
   }
   const size_t R = (size_t)h->R, N = h->N, S = h->S, NI = std::max(h->NI, 1);
@@ -632,7 +672,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
-    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
+    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
     fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
     fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.st.mask); fr(n.d_dsigma); fr(n.d_dcraw);
   }

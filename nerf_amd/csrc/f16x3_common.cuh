@@ -1,0 +1,228 @@
+// f16x3_common.cuh -- machinery of the SPLIT-f16 MLP forward kernel (gfx950, v_mfma_f32_32x32x16_f16): fp32-grade
+// results at matrix-core rates.
+//
+// Every fp32 operand x is split into two halves of 11 significant bits,
+//     x  =  hi + lo / 2048 ,   hi = f16(x) ,   lo = f16((x - hi) * 2048)
+// (x - hi is exact in fp32; the scaling keeps lo a NORMAL f16 whenever hi is, so no bits are lost to f16's narrow
+// exponent range), and a product of two such numbers is taken as three MFMA terms in two fp32 accumulators:
+//     accM += w_hi . x_hi                      accL += w_hi . x_lo + w_lo . x_hi          result = accM + accL / 2048
+// The dropped term w_lo . x_lo is 2^-22 of the product and each half carries 22 bits, so one layer's output is as
+// close to the exact dot product as an fp32 fmaf chain in a different order is (measured on the golden networks:
+// max |err| 1.9e-6 against 2.0e-6 for plain fp32) -- while the three MFMAs run at the f16 rate: 2.5 PF / 3 = 833 TF
+// of fp32-grade contraction against the 157 TF of v_mfma_f32_32x32x2_f32.  Range: |x| and |w| must stay below 65504
+// (f16 max); the network's activations are O(1..10^2).
+//
+// Structure: that of the bf16 kernels (bf16_common.cuh) -- transposed formulation, output-tile-outer loop, weight
+// fragments through a 4 x 32 KiB LDS ring fed by LDS-DMA, asm ds_read_b128 with counted lgkmcnt, the epilogue of
+// tile t cut into pieces that issue between the MFMAs of tile t+1 -- with these differences: the stream carries a
+// (hi, lo) PAIR of 1-KiB fragments per (output tile, k-step); a step is one pair and three MFMAs; activations are
+// kept as (hi, lo) operand pairs, which needs the 512-register file: ONE wave per SIMD, 4 waves (128 samples) per
+// workgroup.
+#pragma once
+#include "mlp_common.cuh"
+#ifndef NH_X3_PD
+#define NH_X3_PD 2
+#endif
+
+namespace nh {
+namespace x3 {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+constexpr int kWaves = 4;              // one per SIMD
+constexpr int kTileSamples = kWaves * 32;
+constexpr int kBlkFrags = 32;          // 1-KiB fragments per ring block = 16 (hi, lo) pairs
+constexpr int kBlkPairs = kBlkFrags / 2;
+constexpr int kBlkBytes = kBlkFrags * 1024;
+constexpr int kRing = 4;
+constexpr int kPD = NH_X3_PD;                 // pairs fetched ahead
+constexpr int kSyncPair = kBlkPairs - kPD - 1;
+constexpr int kDmaPieces = kBlkBytes / kWaves / 1024;   // LDS-DMA instructions per wave per block (8)
+
+// feature (inside a 32-feature tile) held by element e of k-step s in lane half h: as the bf16 MFMA of the same shape
+__device__ __host__ constexpr int feature(int s, int h, int e) { return 16 * s + (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+__device__ __forceinline__ void wait_vm_at_most(int n) {   // s_waitcnt vmcnt(<= n), n >= 8, wave-uniform
+  if (n >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+  else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+struct Ring {
+  const char* stream;   // packed fragment pairs (global), nblk blocks, consumed cyclically
+  float* ring;
+  uint32_t ring_addr;   // LDS byte address of slot 0 + lane*16
+  int nblk, blk, req, req_src, wave, lane;
+  __device__ __forceinline__ void request() {
+    const char* src = stream + (size_t)req_src * kBlkBytes + wave * (kBlkBytes / kWaves) + lane * 16;
+    char* dst = reinterpret_cast<char*>(ring) + (req & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / kWaves);
+#pragma unroll
+    for (int p = 0; p < kDmaPieces; ++p)
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + p * 1024), NERFHIP_LPTR(dst + p * 1024), 16, 0, 0);
+    asm volatile("" ::: "memory");
+    ++req;
+    req_src = req_src + 1 == nblk ? 0 : req_src + 1;
+  }
+  __device__ __forceinline__ void start() {   // blocks 0..2 requested, block 0 visible
+    blk = 0; req = 0; req_src = 0;
+    asm volatile("" ::: "memory");
+    request(); request(); request();
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kDmaPieces) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // sync point P_blk: block blk+1 visible to every wave, slot of block blk-1 handed to block blk+3.  vmcnt retires in
+  // order: at most the pieces of block blk+2 may still be outstanding (the kernel's own stores only make it stricter)
+  __device__ __forceinline__ void sync_point() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kDmaPieces) : "memory");
+    __builtin_amdgcn_s_barrier();
+    request();
+  }
+  __device__ __forceinline__ uint32_t slot_addr(int b) const { return ring_addr + (uint32_t)(b & (kRing - 1)) * kBlkBytes; }
+};
+
+template <int IMM>
+__device__ __forceinline__ void lds_read_frag(f16x8& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+template <int IMM>
+__device__ __forceinline__ void lds_read_f4(f32x4& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm_n() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N)); }
+
+struct BiasBuf { f32x4 q[4]; };
+template <int OT_>
+__device__ __forceinline__ void bias_read(BiasBuf& b, uint32_t addr) {   // addr: vector base + h*16
+  lds_read_f4<(32 * OT_ + 0) * 4>(b.q[0], addr);
+  lds_read_f4<(32 * OT_ + 8) * 4>(b.q[1], addr);
+  lds_read_f4<(32 * OT_ + 16) * 4>(b.q[2], addr);
+  lds_read_f4<(32 * OT_ + 24) * 4>(b.q[3], addr);
+}
+__device__ __forceinline__ f32x16 bias_value(BiasBuf& b) {   // call only behind the wait that retired the reads
+  asm volatile("" : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]));
+  f32x16 c;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { c[4 * q] = b.q[q][0]; c[4 * q + 1] = b.q[q][1]; c[4 * q + 2] = b.q[q][2]; c[4 * q + 3] = b.q[q][3]; }
+  return c;
+}
+
+// a (hi, lo) operand pair of one k-step: 8 f16 each
+struct Pair { f16x8 hi, lo; };
+// split two fp32 values into element pair i (0..3) of an operand pair
+__device__ __forceinline__ void split_into(Pair& p, int i, float v0, float v1) {
+  const f32x2 v = {v0, v1};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 r = {fmaf((float)h[0], -kLoScale, v0 * kLoScale), fmaf((float)h[1], -kLoScale, v1 * kLoScale)};
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  p.hi[2 * i] = h[0]; p.hi[2 * i + 1] = h[1];
+  p.lo[2 * i] = l[0]; p.lo[2 * i + 1] = l[1];
+}
+
+// ---- one layer part: OT output tiles x KS k-steps; step j = ot*KS + ks consumes fragment pair j ----------------
+// BSel:  template <int KS_IDX> const Pair& b() const            B operand pair of k-step KS_IDX
+// Epi:   static constexpr int kPieces;  template <int OT_IDX, int P> void piece(const f32x16& accM, const f32x16& accL)
+//        the epilogue of a finished output tile, cut into kPieces pieces spread over the k-steps of the NEXT tile
+template <int KS, int OT, bool BIAS = true>
+struct PartSched {
+  static constexpr int NF = KS * OT;
+  static constexpr int kBiasStep = 1;
+  // LDS operations issued behind the newest operation step j depends on, up to the wait of step j (replay of the
+  // issue order: prime = init rows of tile 0 (4 reads) + pairs 0..min(kPD,NF)-1 (2 reads each); step t: pair t+kPD,
+  // then (t % KS == kBiasStep) the init rows of the next tile)
+  static constexpr int pending(int j) {
+    int pos = BIAS ? 4 : 0, need = (j == 0) ? pos : 0;
+    for (int f = 0; f < (NF < kPD ? NF : kPD); ++f) { pos += 2; if (f == j) need = pos; }
+    for (int t = 0; t <= j; ++t) {
+      if (t + kPD < NF) { pos += 2; if (t + kPD == j && pos > need) need = pos; }
+      if (BIAS && t % KS == kBiasStep && t / KS + 1 < OT) { pos += 4; if ((t / KS + 1) * KS == j && pos > need) need = pos; }
+    }
+    return pos - need;
+  }
+  static constexpr bool sync_after(int j) { return (j % kBlkPairs == kSyncPair) || (j == NF - 1 && (j % kBlkPairs) < kSyncPair); }
+};
+
+template <int KS, int NP>
+constexpr int piece_offset(int p) { return (p * KS) / NP; }
+template <int KS, class Epi, int OT_IDX, int OFF, int P = 0>
+struct EpiPieces {   // runs the pieces of tile OT_IDX scheduled at k-step offset OFF (OFF < 0: all)
+  static __device__ __forceinline__ void run(Epi& epi, const f32x16& aM, const f32x16& aL) {
+    if constexpr (P < Epi::kPieces) {
+      if constexpr (OFF < 0 || piece_offset<KS, Epi::kPieces>(P) == OFF) epi.template piece<OT_IDX, P>(aM, aL);
+      EpiPieces<KS, Epi, OT_IDX, OFF, P + 1>::run(epi, aM, aL);
+    }
+  }
+};
+
+template <int KS, int OT, class BSel, class Epi, bool BIAS, int J>
+struct PartStep {
+  using S = PartSched<KS, OT, BIAS>;
+  static __device__ __forceinline__ void run(Ring& rg, int blk0, uint32_t bias_addr, f16x8 (&fr)[kPD + 1][2], BiasBuf& bias,
+                                             f32x16 (&accM)[2], f32x16 (&accL)[2], const BSel& bsel, Epi& epi) {
+    constexpr int ot = J / KS, ks = J % KS;
+    if constexpr (J + kPD < S::NF) {
+      constexpr int jj = J + kPD;
+      lds_read_frag<((2 * jj) % kBlkFrags) * 1024>(fr[jj % (kPD + 1)][0], rg.slot_addr(blk0 + jj / kBlkPairs));
+      lds_read_frag<((2 * jj + 1) % kBlkFrags) * 1024>(fr[jj % (kPD + 1)][1], rg.slot_addr(blk0 + jj / kBlkPairs));
+    }
+    if constexpr (BIAS && ks == S::kBiasStep && ot + 1 < OT) bias_read<ot + 1>(bias, bias_addr);
+    wait_lgkm_n<(S::pending(J) < 15 ? S::pending(J) : 15)>();   // lgkmcnt is a 4-bit counter: a smaller count is only stricter
+    asm volatile("" : "+v"(fr[J % (kPD + 1)][0]), "+v"(fr[J % (kPD + 1)][1]));
+    const f16x8& wh = fr[J % (kPD + 1)][0];
+    const f16x8& wl = fr[J % (kPD + 1)][1];
+    const Pair& b = bsel.template b<ks>();
+    if constexpr (ks == 0) {
+      f32x16 c0, z0;
+      if constexpr (BIAS) c0 = bias_value(bias);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { z0[r] = 0.f; if constexpr (!BIAS) c0[r] = 0.f; }
+      accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.hi, c0, 0, 0, 0);
+      accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.lo, z0, 0, 0, 0);
+    } else {
+      accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.hi, accM[ot & 1], 0, 0, 0);
+      accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.lo, accL[ot & 1], 0, 0, 0);
+    }
+    accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b.hi, accL[ot & 1], 0, 0, 0);
+    if constexpr (ot >= 1) EpiPieces<KS, Epi, ot - 1, ks>::run(epi, accM[(ot - 1) & 1], accL[(ot - 1) & 1]);
+    if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<KS, Epi, ot, -1>::run(epi, accM[ot & 1], accL[ot & 1]);
+    if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkPairs; rg.sync_point(); }
+    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, BIAS, J + 1>::run(rg, blk0, bias_addr, fr, bias, accM, accL, bsel, epi);
+  }
+};
+
+template <int NF, int F>
+__device__ __forceinline__ void prime_pairs(f16x8 (&fr)[kPD + 1][2], uint32_t addr) {   // pairs 0..min(kPD,NF)-1
+  if constexpr (F < kPD && F < NF) {
+    lds_read_frag<(2 * F) * 1024>(fr[F][0], addr);
+    lds_read_frag<(2 * F + 1) * 1024>(fr[F][1], addr);
+    prime_pairs<NF, F + 1>(fr, addr);
+  }
+}
+// Runs one part that starts at block rg.blk (block-aligned) and leaves rg.blk at the next part's first block.
+template <int KS, int OT, bool BIAS = true, class BSel, class Epi>
+__device__ __forceinline__ void run_part(Ring& rg, uint32_t bias_addr, const BSel& bsel, Epi& epi) {
+  static_assert(!BIAS || KS >= 2 || OT == 1, "the init rows of the next tile are requested at k-step 1");
+  static_assert(kPD < kBlkPairs, "the prefetch must stay inside the block after the current one");
+  using S = PartSched<KS, OT, BIAS>;
+  const int blk0 = rg.blk;
+  f16x8 fr[kPD + 1][2];
+  BiasBuf bias;
+  f32x16 accM[2], accL[2];
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (BIAS) bias_read<0>(bias, bias_addr);
+  prime_pairs<S::NF, 0>(fr, rg.slot_addr(blk0));
+  PartStep<KS, OT, BSel, Epi, BIAS, 0>::run(rg, blk0, bias_addr, fr, bias, accM, accL, bsel, epi);
+  wait_lgkm_n<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  rg.blk = blk0 + (S::NF + kBlkPairs - 1) / kBlkPairs;
+}
+
+}  // namespace x3
+}  // namespace nh

@@ -1,0 +1,255 @@
+// mlp_fwd_f16x3.hip -- fused positional-encoding + density/colour MLP forward with SPLIT-f16 MFMA operands (gfx950),
+// inference: the function of mlp_fwd.hip (reference nerf/nerfCoreBlock.scala:17-112) to fp32 accuracy at matrix-core
+// rates (f16x3_common.cuh: x = hi + lo/2048, three v_mfma_f32_32x32x16_f16 per product, two fp32 accumulators).
+// Held to the SAME parity bars as the fp32 kernels (tests: every fp32 render test also runs with dtype f16x3).
+// Positions, the encoding's sin/cos (accurate sinf/cosf, not the hardware approximations of the bf16 path), biases,
+// the per-ray view-direction branch and all accumulators are fp32.
+// One wave = 32 samples x all features, one wave per SIMD (512 registers), workgroup = 4 waves = 128 samples,
+// persistent (one per CU).  Stream layout = that of the bf16 kernel with every fragment replaced by its (hi, lo) pair
+// and every part padded to whole 16-pair blocks (api.hip: build_bf16_streams(pad 16) + pack.hip: pack_frags_f16x3).
+#include "f16x3_common.cuh"
+#include <algorithm>
+#include "launchers.h"
+
+namespace nh {
+namespace x3 {
+
+template <int WT>
+struct ActRegs { Pair v[WT][2]; };   // [k-tile][k-step]
+
+template <int WT>
+struct SelAct {   // k-steps 0 .. 2WT-1: previous layer; 2WT .. 2WT+3: encoding (skip layers)
+  const ActRegs<WT>& a;
+  const ActRegs<2>* e;
+  template <int KS_IDX> __device__ __forceinline__ const Pair& b() const {
+    if constexpr (KS_IDX < 2 * WT) return a.v[KS_IDX / 2][KS_IDX % 2];
+    else return e->v[(KS_IDX - 2 * WT) / 2][KS_IDX % 2];
+  }
+};
+struct SelEnc {
+  const ActRegs<2>& e;
+  template <int KS_IDX> __device__ __forceinline__ const Pair& b() const { return e.v[KS_IDX / 2][KS_IDX % 2]; }
+};
+template <int HT>
+struct SelHid {
+  const ActRegs<HT>& a;
+  template <int KS_IDX> __device__ __forceinline__ const Pair& b() const { return a.v[KS_IDX / 2][KS_IDX % 2]; }
+};
+
+// accM + accL/2048 of accumulator register R_
+template <int R_>
+__device__ __forceinline__ float merged(const f32x16& aM, const f32x16& aL) { return fmaf(aL[R_], kLoInv, aM[R_]); }
+
+template <int WT>
+struct EpiTrunk {   // relu + split -> B operand pairs of the next layer; piece P = registers 2P, 2P+1 of the tile
+  ActRegs<WT>& out;
+  static constexpr int kPieces = 8;
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& aM, const f32x16& aL) {
+    const float v0 = fmaxf(merged<2 * P>(aM, aL), 0.f), v1 = fmaxf(merged<2 * P + 1>(aM, aL), 0.f);
+    split_into(out.v[OT_IDX][P / 4], P % 4, v0, v1);
+  }
+};
+struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
+  float* sigma; int m; bool valid; int h;
+  static constexpr int kPieces = 1;
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& aM, const f32x16& aL) {
+    if (valid && h == 0) sigma[m] = merged<0>(aM, aL);
+  }
+};
+template <int HT, int MODE>
+struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
+  ActRegs<HT>& hid; float (&c)[3];
+  const float* dirfeat; int ray; int m; bool valid; float* sigma; int h;
+  static constexpr int kPieces = 8;
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& aM, const f32x16& aL) {
+    const float a0 = merged<2 * P>(aM, aL), a1 = merged<2 * P + 1>(aM, aL);
+    if constexpr (OT_IDX == HT) {
+      if constexpr (P == 0)
+        if (valid && h == 0) sigma[m] = a0;
+    } else if constexpr (MODE == 1) {
+      // add().relu() (nerfCoreBlock.scala:67): + (Wd.enc(dir) + bd + bf) of the sample's ray, fp32; registers 2P, 2P+1
+      // hold features 32 OT + 8 (P/2) + 2 (P%2) + 4h + {0, 1}
+      const float* df = dirfeat + (int64_t)ray * (32 * HT) + 32 * OT_IDX + 8 * (P / 2) + 2 * (P % 2) + 4 * h;
+      const f32x2 d = *reinterpret_cast<const f32x2*>(df);
+      split_into(hid.v[OT_IDX][P / 4], P % 4, fmaxf(a0 + d[0], 0.f), fmaxf(a1 + d[1], 0.f));
+    } else if constexpr (MODE == 2) {
+      // reshape(...,9,3).mul(SH).sum(-2) (:55): c[k] = sum_j q[3j+k] * Y_j(dir); rows 0..26 of tile 0
+      const float* Y = dirfeat + (int64_t)ray * 12;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = tile_row(0, 2 * P + i, h);
+        if (row < 27) {
+          const int j = row / 3, k = row - 3 * j;
+          const float v = (i == 0 ? a0 : a1) * Y[j];
+          c[0] += k == 0 ? v : 0.f; c[1] += k == 1 ? v : 0.f; c[2] += k == 2 ? v : 0.f;
+        }
+      }
+    } else {
+      if (h == 0) {
+        if constexpr (P == 0) { c[0] = a0; c[1] = a1; }
+        if constexpr (P == 1) c[2] = a0;
+      }
+    }
+  }
+};
+struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
+  float (&c)[3]; int h;
+  static constexpr int kPieces = 2;
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& aM, const f32x16& aL) {
+    if (h == 0) {
+      if constexpr (P == 0) { c[0] = merged<0>(aM, aL); c[1] = merged<1>(aM, aL); }
+      if constexpr (P == 1) c[2] = merged<2>(aM, aL);
+    }
+  }
+};
+
+// positionCode (nerfCoreBlock.scala:127-136) of this lane's 32 of the 64 (padded) features, split into operand pairs
+template <int H>
+__device__ __forceinline__ void encode_half(ActRegs<2>& enc, float px, float py, float pz, int E) {
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        split_into(enc.v[kt][s], i, code_value(px, py, pz, 32 * kt + feature(s, H, 2 * i), E),
+                   code_value(px, py, pz, 32 * kt + feature(s, H, 2 * i + 1), E));
+}
+
+template <int WT, int MODE>
+__global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs net, const char* __restrict__ stream,
+                                                                       const float* __restrict__ bvec,
+                                                                       const float* __restrict__ rays_o,
+                                                                       const float* __restrict__ rays_d,
+                                                                       const float* __restrict__ z,
+                                                                       const float* __restrict__ dirfeat, int64_t M, int S,
+                                                                       float* __restrict__ sigma, float* __restrict__ craw,
+                                                                       int want_rgb, int nblk, int ntiles) {
+  constexpr int R = 32 * WT;
+  constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
+  extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring (kRing x 32 KiB) | vectors
+  float* vec = smem + kRing * kBlkBytes / 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = net.D;
+  const int nvec = D * R + (HT + 1) * 32 + 32;
+
+  Ring rg;
+  rg.stream = stream;
+  rg.ring = smem;
+  rg.ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem + (uint32_t)lane * 16u;
+  rg.wave = wave;
+  rg.lane = lane;
+  rg.nblk = nblk;
+  for (int i = tid; i < nvec; i += 64 * kWaves) vec[i] = bvec[i];
+  const uint32_t vec_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)vec + (uint32_t)h * 16u;
+
+  __syncthreads();   // vectors visible
+  rg.start();
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m = tile * kTileSamples + wave * 32 + li;   // host guarantees M < 2^31
+    const bool valid = m < (int)M;
+    const int mc = valid ? m : (int)M - 1;
+    const int ray = (int)((uint32_t)mc / (uint32_t)S);
+    // sample position (raysO.add(raysD.mul(zVals)), nerfBlock.scala:65): separate mul and add, fp32
+    const float zz = z[mc];
+    const float px = __fadd_rn(rays_o[(int64_t)ray * 3 + 0], __fmul_rn(rays_d[(int64_t)ray * 3 + 0], zz));
+    const float py = __fadd_rn(rays_o[(int64_t)ray * 3 + 1], __fmul_rn(rays_d[(int64_t)ray * 3 + 1], zz));
+    const float pz = __fadd_rn(rays_o[(int64_t)ray * 3 + 2], __fmul_rn(rays_d[(int64_t)ray * 3 + 2], zz));
+    // the encoding is computed once per sample and kept (32 registers) for the skip layers: its sin/cos are the
+    // accurate ones, far too expensive to recompute
+    ActRegs<2> enc;
+    if (h == 0) encode_half<0>(enc, px, py, pz, net.E);
+    else encode_half<1>(enc, px, py, pz, net.E);
+
+    ActRegs<WT> act, nxt;
+    {
+      EpiTrunk<WT> epi{act};
+      run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
+    }
+    auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) {
+      EpiTrunk<WT> epi{out};
+      const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
+      if ((net.skip_mask >> (l - 1)) & 1u) run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{in, &enc}, epi);
+      else run_part<2 * WT, WT>(rg, baddr, SelAct<WT>{in, nullptr}, epi);
+    };
+    int l = 1;
+    for (; l + 1 < D; l += 2) {
+      layer(l, act, nxt);
+      layer(l + 1, nxt, act);
+    }
+    if (l < D) {
+      layer(l, act, nxt);
+      act = nxt;
+    }
+
+    const uint32_t haddr = vec_addr + (uint32_t)(D * R) * 4u;
+    if (!want_rgb) {
+      // sigma-only stream: one tile, row 0 = density row (nerfCoreBlock.scala:39-40)
+      EpiSigma epi{sigma, m, valid, h};
+      run_part<2 * WT, 1>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, nullptr}, epi);
+      continue;
+    }
+    // head: HT colour tiles, then the density tile
+    ActRegs<HT> hid;
+    float c[3] = {0.f, 0.f, 0.f};
+    EpiHead<HT, MODE> epih{hid, c, dirfeat, ray, m, valid, sigma, h};
+    run_part<2 * WT, HT + 1>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
+    if constexpr (MODE == 1) {
+      // colour output layer: Linear(3) over the H2 hidden features, as one MFMA tile (rows 0..2)
+      EpiColour epic{c, h};
+      run_part<2 * HT, 1>(rg, haddr + (uint32_t)((HT + 1) * 32) * 4u, SelHid<HT>{hid}, epic);
+    } else if constexpr (MODE == 2) {
+      c[0] += __shfl_xor(c[0], 32); c[1] += __shfl_xor(c[1], 32); c[2] += __shfl_xor(c[2], 32);
+    }
+    if (valid && h == 0) { craw[(int64_t)m * 3 + 0] = c[0]; craw[(int64_t)m * 3 + 1] = c[1]; craw[(int64_t)m * 3 + 2] = c[2]; }
+  }   // tile loop
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+template <int WT, int MODE>
+static hipError_t launch_one(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o, const float* rays_d,
+                             const float* z, const float* dirfeat, int64_t M, int S, float* sigma, float* craw, int want_rgb,
+                             int nblk, int n_cu, hipStream_t stream) {
+  constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
+  const size_t lds = (size_t)kRing * kBlkBytes + ((size_t)net.D * 32 * WT + (HT + 1) * 32 + 32) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);
+  const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kWaves);   // one persistent workgroup per CU
+  hipLaunchKernelGGL((mlp_fwd_f16x3_kernel<WT, MODE>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o, rays_d,
+                     z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles);
+  return hipGetLastError();
+}
+
+}  // namespace x3
+
+#define NH_X3_CASES(F)                                                                                                  \
+  switch ((W / 32) * 4 + mode) {                                                                                        \
+    case 2 * 4 + 0: F(2, 0); case 2 * 4 + 1: F(2, 1); case 2 * 4 + 2: F(2, 2);                                          \
+    case 4 * 4 + 0: F(4, 0); case 4 * 4 + 1: F(4, 1); case 4 * 4 + 2: F(4, 2);                                          \
+    case 8 * 4 + 0: F(8, 0); case 8 * 4 + 1: F(8, 1); case 8 * 4 + 2: F(8, 2);                                          \
+    default: return hipErrorInvalidValue;                                                                               \
+  }
+
+// once per device, with that device current (nerfhip_create)
+hipError_t prepare_mlp_fwd_f16x3(int W, int mode) {
+#define NH_X3_PREP(WT_, MODE_) \
+  return hipFuncSetAttribute((const void*)x3::mlp_fwd_f16x3_kernel<WT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  NH_X3_CASES(NH_X3_PREP)
+#undef NH_X3_PREP
+}
+
+// stream_w: the full pair stream when want_rgb, else the sigma-only one (api.hip)
+hipError_t launch_mlp_fwd_f16x3(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+                                const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
+                                float* craw, int want_rgb, int nblk, int n_cu, hipStream_t stream) {
+  const int W = net.W, mode = net.mode;
+#define NH_X3_LAUNCH(WT_, MODE_) \
+  return x3::launch_one<WT_, MODE_>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream)
+  NH_X3_CASES(NH_X3_LAUNCH)
+#undef NH_X3_LAUNCH
+}
+
+}  // namespace nh

@@ -46,6 +46,29 @@ __global__ __launch_bounds__(64) void pack_frags_bf16_kernel(const float* __rest
   }
 }
 
+// split-f16 weight streams (f16x3_common.cuh): descriptor i -> fragment 2i = hi = f16(w), fragment 2i+1 = lo =
+// f16((w - hi) * 2048); same lane / element order as the bf16 fragments
+__global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __restrict__ params,
+                                                              const FragDesc* __restrict__ descs,
+                                                              _Float16* __restrict__ dst) {
+  const FragDesc d = descs[blockIdx.x];
+  const int lane = threadIdx.x, h = lane >> 5, i = lane & 31;
+  const float* src = params + (d.src_off < 0 ? 0 : d.src_off);
+  _Float16* oh = dst + ((int64_t)(2 * blockIdx.x) * 64 + lane) * 8;
+  _Float16* ol = oh + 512;
+  const int row = d.row0 + i;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int f = 16 * d.s + (e & 3) + 8 * (e >> 2) + 4 * h;
+    float v = 0.f;
+    if (d.src_off >= 0 && row < d.nrows && f < d.kvalid)
+      v = d.transposed ? src[(int64_t)(d.col0 + f) * d.ld + row] : src[(int64_t)row * d.ld + d.col0 + f];
+    const _Float16 hi = (_Float16)v;
+    oh[e] = hi;
+    ol[e] = (_Float16)(__fmul_rn(__fsub_rn(v, (float)hi), 2048.0f));
+  }
+}
+
 // bf16 path vectors (fp32): [D*W] trunk biases | [(HT+1)*32] head accumulator init (mode 1: zero, the per-ray
 // direction vector carries bf + bd; else bf; tile HT: b_sigma at row 0) | [32] colour bias (mode 1)
 __global__ void pack_bvec_kernel(const float* __restrict__ params, NetLayout L, int HT, float* __restrict__ bv) {
@@ -216,6 +239,11 @@ hipError_t launch_pack_chunks(const float* params, const ChunkDesc* descs, int n
 hipError_t launch_pack_frags_bf16(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(pack_frags_bf16_kernel, dim3(n), dim3(64), 0, s, params, descs, (__bf16*)dst);
+  return hipGetLastError();
+}
+hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_frags_f16x3_kernel, dim3(n), dim3(64), 0, s, params, descs, (_Float16*)dst);
   return hipGetLastError();
 }
 hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s) {

@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 ANGLE = 0.6911112070083618
 
 
-def test_config0_tiny_frame_matches_cpu_path():
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_config0_tiny_frame_matches_cpu_path(dtype):
     c = H.cfg(D=4, W=64, skips=[2], posL=6, dirL=2, NSamples=64, NImportance=0, useHierarchical=False)
     HW = 100
     focal = 0.5 * HW / math.tan(0.5 * ANGLE)
@@ -31,7 +32,7 @@ def test_config0_tiny_frame_matches_cpu_path():
     params = H.make_params(c, 5)
     ro, rd, bd = o.gen_rays(HW, HW, focal, pose, 2.0, 6.0, False)
     ref = o.forward(params, ro, rd, bd, rd)["rgb_fine"]                       # the CPU path, 10 000 rays
-    blk = G.make_block(c, max_rays=4096)
+    blk = G.make_block(c, max_rays=4096, dtype=dtype)
     blk.set_params(params)
     try:
         img = blk.render_pose(HW, HW, focal, pose, 2.0, 6.0, False)           # rays generated on the device
@@ -45,7 +46,7 @@ def test_config0_tiny_frame_matches_cpu_path():
         blk.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16"])
 def test_config2_row_sharded_frame_equals_whole_frame(dtype):
     c = dict(H.CONFIGS["full"], dtype=dtype)
     Himg, Wimg, world = 800, 16, 8                 # all 800 rows (the sharded axis) of a 16-pixel-wide strip

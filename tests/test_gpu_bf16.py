@@ -198,7 +198,7 @@ def test_psnr_after_fixed_steps_bf16(G):
     blk.close()
 
 
-@pytest.mark.parametrize("dtype,atol", [("f32", 2e-4), ("bf16", 1e-2)])
+@pytest.mark.parametrize("dtype,atol", [("f32", 2e-4), ("f16x3", 2e-4), ("bf16", 1e-2)])
 def test_config5_ndc_rays_256_fine_samples(G, dtype, atol):
     """BASELINE configs[4] in small: forward-facing NDC rays (llff.scala:96-132, getDataSet.scala:112 bounds
     (0, |d'|)) generated on the device, full 8x256 network with 64 + 256 samples per ray (S_fine = 320), against

@@ -141,16 +141,28 @@ def test_composite_fwd(G, S, white):
 MLP_CASES = ["small_dir_eval", "small_sh_eval", "small_nodir_train", "small_flat_eval", "full_eval"]
 
 
+# every fp32 render test also runs on the split-f16 kernels (dtype "f16x3": three f16 MFMAs per product, fp32-grade),
+# at the SAME tolerances; W = 32 networks exist only in fp32
+DTYPES = ["f32", "f16x3"]
+
+
+def _skip_unsupported(c, dtype):
+    if dtype == "f16x3" and c["W"] == 32:
+        pytest.skip("the split-f16 kernels need W = 64, 128 or 256")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", MLP_CASES)
-def test_mlp_forward_stage(G, case):
+def test_mlp_forward_stage(G, case, dtype):
     """Fused posenc+MLP kernel on the golden's own fine depths vs the oracle and the golden (fp32 MFMA:
-    only the GEMM summation order and 1-2 ulp sin/cos differ)."""
+    only the GEMM summation order and 1-2 ulp sin/cos differ; split-f16: the same bar)."""
     name = case.rsplit("_", 1)[0]
     c = H.CONFIGS[name]
+    _skip_unsupported(c, dtype)
     g = load(case)
     o = Oracle(c)
     params = H.make_params(c, int(g["seed"]))
-    blk = G.make_block(c)
+    blk = G.make_block(c, dtype=dtype)
     blk.set_params(params)
     n, S = g["z_fine"].shape
     net = 1 if c["useHierarchical"] else 0
@@ -224,7 +236,8 @@ def test_mlp_forward_stage_tight(G, case):
     blk.close()
 
 
-def test_mlp_forward_ragged_tile(G):
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mlp_forward_ragged_tile(G, dtype):
     """n*S not a multiple of the 128-sample workgroup tile; coarse network without colour head."""
     c = H.CONFIGS["small_dir"]
     o = Oracle(c)
@@ -232,7 +245,7 @@ def test_mlp_forward_ragged_tile(G):
     ro, rd, b, _ = H.make_rays(n, 8)
     z = np.sort(H.det_uniform(n * S, 5, 2.0, 6.0).reshape(n, S), axis=1)
     params = H.make_params(c, 3)
-    blk = G.make_block(c)
+    blk = G.make_block(c, dtype=dtype)
     blk.set_params(params)
     sig = G.empty(n, S)
     blk.k_mlp_forward(0, G.dev(ro), G.dev(rd), G.dev(rd), G.dev(z), n, S, sig, None)
@@ -245,8 +258,9 @@ def test_mlp_forward_ragged_tile(G):
 E2E = ["small_dir_eval", "small_sh_eval", "small_flat_eval", "small_opts_eval", "full_eval"]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", E2E)
-def test_render_end_to_end(G, case):
+def test_render_end_to_end(G, case, dtype):
     """nerfhip_render (host pointers) vs oracle and golden.  Sample depths bit-exact; per-sample tensors as a
     fraction within tolerance (a 1-ulp depth difference is amplified by the 2^(posL-1) encoding, see
     test_oracle_golden.py); composited rgb within 2e-4 abs, depth 2e-4 rel."""
@@ -256,7 +270,7 @@ def test_render_end_to_end(G, case):
     o = Oracle(c)
     params = H.make_params(c, int(g["seed"]))
     rand = {k[5:]: v for k, v in g.items() if k.startswith("rand_")}
-    blk = G.make_block(c)
+    blk = G.make_block(c, dtype=dtype)
     blk.set_params(params)
     fine, coarse, dbg = blk.forward(g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], training=False, rand=rand, debug=True)
     ref = o.forward(params, g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], training=False, rand=rand)
@@ -279,9 +293,14 @@ def test_render_end_to_end(G, case):
     # sampler, not the network.  2e-6 of the output scale (sin/cos ulps), as test_mlp_forward_stage_tight.
     npc = o.net_param_count()
     net = 1 if c["useHierarchical"] else 0
-    ks, kc = o.mlp_forward_korder(params[npc * net:npc * (net + 1)], True, g["rays_o"], g["rays_d"], g["rays_d"], dbg["z_fine"])
-    assert np.abs(dbg["sigma_f"][:, :S - 1] - ks[:, :S - 1]).max() <= 2e-6 * np.abs(ks).max()
-    assert np.abs(dbg["craw_f"] - kc).max() <= 2e-6 * np.abs(kc).max()
+    if dtype == "f32":
+        ks, kc = o.mlp_forward_korder(params[npc * net:npc * (net + 1)], True, g["rays_o"], g["rays_d"], g["rays_d"], dbg["z_fine"])
+        assert np.abs(dbg["sigma_f"][:, :S - 1] - ks[:, :S - 1]).max() <= 2e-6 * np.abs(ks).max()
+        assert np.abs(dbg["craw_f"] - kc).max() <= 2e-6 * np.abs(kc).max()
+    else:   # split-f16 sums in its own order: every sample at the MLP-stage bar of the fp32 kernels
+        ks, kc = o.mlp_forward(params[npc * net:npc * (net + 1)], False, True, g["rays_o"], g["rays_d"], g["rays_d"], dbg["z_fine"])
+        np.testing.assert_allclose(dbg["sigma_f"][:, :S - 1], ks[:, :S - 1], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(dbg["craw_f"], kc, rtol=2e-4, atol=2e-5)
     for r in (ref, g):
         np.testing.assert_allclose(fine, r["rgb_fine"], rtol=0, atol=2e-4)
         np.testing.assert_allclose(dbg["depth"], r["depth"], rtol=1e-3)  # end to end: an isolated moved sample
@@ -289,14 +308,15 @@ def test_render_end_to_end(G, case):
     blk.close()
 
 
-def test_render_chunking_and_u8(G):
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_render_chunking_and_u8(G, dtype):
     """n > max_rays is processed in slices; uint8 rows are *255, clamp, truncate (runNerf.scala:194)."""
     c = H.CONFIGS["small_sh"]
     o = Oracle(c)
     n = 300
     ro, rd, b, _ = H.make_rays(n, 12)
     params = H.make_params(c, 4)
-    blk = G.make_block(c, max_rays=128)
+    blk = G.make_block(c, max_rays=128, dtype=dtype)
     blk.set_params(params)
     fine = blk.evaluate(ro, rd, b, rd)
     ref = o.forward(params, ro, rd, b, rd)["rgb_fine"]

@@ -135,6 +135,25 @@ def test_adam_step_matches_oracle(G):
     blk.close(); blk2.close()
 
 
+def test_f16x3_handle_trains_on_the_fp32_kernels(G):
+    """dtype "f16x3" changes the RENDER kernels only: a training iteration on such a handle is the fp32 one (same
+    gradients up to the atomics' order), and the render that follows uses the updated weights on both paths."""
+    c = H.CONFIGS["small_dir"]
+    g = load("small_dir_train")
+    params = H.make_params(c, 1)
+    args = (g["rays_o"], g["rays_d"], g["bounds"], g["rays_d"], g["label"])
+    a, b = G.make_block(c, dtype="f16x3"), G.make_block(c)
+    for blk in (a, b):
+        blk.set_params(params)
+        blk.train_backward(*args)
+    ga, gb = a.get_grads(), b.get_grads()
+    np.testing.assert_allclose(ga, gb, rtol=0, atol=2e-6 * np.abs(gb).max())
+    for blk in (a, b):
+        blk.optimizer_step()
+    np.testing.assert_allclose(a.evaluate(*args[:4]), b.evaluate(*args[:4]), rtol=0, atol=2e-5)
+    a.close(); b.close()
+
+
 def test_optimizer_step_needs_backward(G):
     from nerf_amd import NerfHipError
     blk = G.make_block(H.CONFIGS["small_dir"])

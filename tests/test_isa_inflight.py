@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.mark.parametrize("src", ["mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "mlp_fwd_bf16.hip", "mlp_bwd_bf16.hip", "wgrad_bf16.hip"])
+@pytest.mark.parametrize("src", ["mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "mlp_fwd_bf16.hip", "mlp_bwd_bf16.hip", "wgrad_bf16.hip",
+                                 "mlp_fwd_f16x3.hip"])
 def test_no_instruction_touches_inflight_registers(src, tmp_path):
     if not os.path.exists(HIPCC) and not shutil.which("hipcc"):
         pytest.skip("hipcc not available")

@@ -9,7 +9,7 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,dtype", [("small_dir", "f32"), ("full", "f32"), ("full", "bf16"), ("shipped", "f32")])
+@pytest.mark.parametrize("name,dtype", [("small_dir", "f32"), ("full", "f32"), ("full", "bf16"), ("shipped", "f32"), ("full", "f16x3")])
 def test_render_dev_static_equals_render_dev(name, dtype):
     import torch
     import gpu_util as G
