@@ -1,10 +1,12 @@
-"""Render-only timing of the full network (400x400 frames): python scripts/bench_render.py [f32|bf16] [frames]"""
+"""Render-only timing of the full network (400x400 frames): python scripts/bench_render.py [f32|bf16|f16x3] [frames]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import helpers as H
-from nerf_amd import NerfBlock, NerfConfig
+from nerf_amd import NerfBlock, NerfConfig, _lib
+if len(sys.argv) > 3:   # an experimental build of the library (development timing only)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[3])
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 c = dict(H.CONFIGS["full"], dtype=dtype)
