@@ -341,22 +341,34 @@ double net_fwd_flop_per_sample(const Net& n, bool want_rgb) {
 
 int repack(nerfhip* h) {
   Scope sc(h, P_OTHER);
+  if (h->cfg.dtype == NERFHIP_BF16) {   // one launch for every stream and vector of every network
+    RepackBf16Args a{};
+    for (int i = 0; i < h->nnets; ++i) {
+      Net& n = h->nets[i];
+      const float* p = h->d_params + n.param_off;
+      auto seg = [&](const FragDesc* d, void* dst, size_t cnt) {
+        a.seg[a.nseg++] = RepackBf16Args::Seg{d, dst, p, a.nfrag, (int32_t)cnt};
+        a.nfrag += (int32_t)cnt;
+      };
+      seg(n.d_bf_full_desc, n.d_bf_full, n.bf_full.size());
+      seg(n.d_bf_sigma_desc, n.d_bf_sigma, n.bf_sigma.size());
+      seg(n.d_bf_bwd_desc, n.d_bf_bwd, n.bf_bwd.size());
+      a.vparams[i] = p; a.bv[i] = n.d_bvec; a.L[i] = n.L; a.HT[i] = n.L.mode == 1 ? std::max(1, n.WT / 2) : 1;
+    }
+    a.nnets = h->nnets;
+    HIPCHK(h, launch_repack_bf16(a, h->stream));
+    h->packed = true;
+    return NERFHIP_OK;
+  }
   for (int i = 0; i < h->nnets; ++i) {
     Net& n = h->nets[i];
     const float* p = h->d_params + n.param_off;
-    if (h->cfg.dtype != NERFHIP_BF16) {   // the fp32 kernels' tile images
-      HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));
-      HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
-      HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
-      if (h->cfg.dtype == NERFHIP_F16X3) {   // + the render kernel's pair streams (training stays on the fp32 kernels)
-        HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->stream));
-        HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, h->stream));
-        HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, h->stream));
-      }
-    } else {
-      HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_full_desc, (int)n.bf_full.size(), n.d_bf_full, h->stream));
-      HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_sigma_desc, (int)n.bf_sigma.size(), n.d_bf_sigma, h->stream));
-      HIPCHK(h, launch_pack_frags_bf16(p, n.d_bf_bwd_desc, (int)n.bf_bwd.size(), n.d_bf_bwd, h->stream));
+    HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));   // fp32 tile images
+    HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
+    HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
+    if (h->cfg.dtype == NERFHIP_F16X3) {   // + the render kernel's pair streams (training stays on the fp32 kernels)
+      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->stream));
+      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, h->stream));
       HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, h->stream));
     }
   }

@@ -10,7 +10,7 @@
 //     of tile t+1's MFMAs, and the converted tile is directly a B operand of the next layer:
 //     accumulator register r = 8s + e of a tile holds feature  F(s,h,e) = 16s + (e&3) + 8(e>>2) + 4h,
 //     so registers 8s..8s+7 of both lane halves are exactly the 16 features of k-step s; the weight fragment of
-//     (k-tile kt, step s, output tile ot) is packed in that same order (pack.hip: pack_frags_bf16_kernel).
+//     (k-tile kt, step s, output tile ot) is packed in that same order (pack.hip: repack_bf16_kernel).
 //
 // Weight stream: one flat sequence of 1-KiB fragments in consumption order, every layer part padded to a
 // multiple of 32 fragments.  It moves through a ring of kRing LDS slots in fixed 32-KiB blocks by LDS-DMA

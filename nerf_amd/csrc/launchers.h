@@ -45,8 +45,18 @@ hipError_t launch_mlp_bwd_f32(const NetArgs& net, const float* d_sigma, const fl
                               int64_t M, int S, int has_rgb, const ActStore& st, hipStream_t stream);
 
 // bf16 path
-hipError_t launch_pack_frags_bf16(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s);
 hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s);
+// all bf16 streams and vectors of up to two networks in one launch (pack.hip: repack_bf16_kernel)
+struct RepackBf16Args {
+  static constexpr int kMaxSeg = 6, kBvecBlocks = 16;
+  struct Seg { const FragDesc* descs; void* dst; const float* params; int32_t first, n; } seg[kMaxSeg];
+  int32_t nseg, nfrag, nnets;
+  int32_t HT[2];
+  const float* vparams[2];
+  float* bv[2];
+  NetLayout L[2];
+};
+hipError_t launch_repack_bf16(const RepackBf16Args& a, hipStream_t s);
 hipError_t launch_mlp_fwd_bf16(const BfStore* st, const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
                                float* craw, int want_rgb, int nblk, int n_cu, hipStream_t stream);

@@ -4,7 +4,7 @@
 //     stream holds W_l, the backward stream W_l^T (so both are the A operand of the same MFMA loop);
 //   * vecpack: 16-byte aligned copies of biases / density row / colour output rows.
 // Runs once per set_params and once after every optimizer step (about 2x the parameter bytes).
-#include "common.h"
+#include "launchers.h"
 #include "rng.cuh"
 
 namespace nh {
@@ -28,13 +28,11 @@ __global__ void pack_chunks_kernel(const float* __restrict__ params, const Chunk
 }
 
 // bf16 weight streams: one block (64 lanes) per fragment; lane (h, i) writes 8 bf16 = W[row0+i][col0 + F(s,h,e)]
-__global__ __launch_bounds__(64) void pack_frags_bf16_kernel(const float* __restrict__ params,
-                                                             const FragDesc* __restrict__ descs,
-                                                             __bf16* __restrict__ dst) {
-  const FragDesc d = descs[blockIdx.x];
-  const int lane = threadIdx.x, h = lane >> 5, i = lane & 31;
+__device__ __forceinline__ void pack_frag_bf16(const float* __restrict__ params, const FragDesc& d, __bf16* __restrict__ dst,
+                                               int frag, int lane) {
+  const int h = lane >> 5, i = lane & 31;
   const float* src = params + (d.src_off < 0 ? 0 : d.src_off);
-  __bf16* o = dst + ((int64_t)blockIdx.x * 64 + lane) * 8;
+  __bf16* o = dst + ((int64_t)frag * 64 + lane) * 8;
   const int row = d.row0 + i;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -45,7 +43,6 @@ __global__ __launch_bounds__(64) void pack_frags_bf16_kernel(const float* __rest
     o[e] = (__bf16)v;
   }
 }
-
 // split-f16 weight streams (f16x3_common.cuh): descriptor i -> fragment 2i = hi = f16(w), fragment 2i+1 = lo =
 // f16((w - hi) * 2048); same lane / element order as the bf16 fragments
 __global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __restrict__ params,
@@ -71,10 +68,11 @@ __global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __res
 
 // bf16 path vectors (fp32): [D*W] trunk biases | [(HT+1)*32] head accumulator init (mode 1: zero, the per-ray
 // direction vector carries bf + bd; else bf; tile HT: b_sigma at row 0) | [32] colour bias (mode 1)
-__global__ void pack_bvec_kernel(const float* __restrict__ params, NetLayout L, int HT, float* __restrict__ bv) {
+__device__ __forceinline__ void pack_bvec_range(const float* __restrict__ params, const NetLayout& L, int HT,
+                                                float* __restrict__ bv, int first, int stride) {
   const int W = L.W, D = L.D;
   const int total = D * W + (HT + 1) * 32 + 32;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+  for (int idx = first; idx < total; idx += stride) {
     float v = 0.f;
     if (idx < D * W) {
       v = params[L.b_off[idx / W] + idx % W];
@@ -88,6 +86,28 @@ __global__ void pack_bvec_kernel(const float* __restrict__ params, NetLayout L, 
       if (L.mode == 1 && j < 3) v = params[L.bc_off + j];
     }
     bv[idx] = v;
+  }
+}
+__global__ void pack_bvec_kernel(const float* __restrict__ params, NetLayout L, int HT, float* __restrict__ bv) {
+  pack_bvec_range(params, L, HT, bv, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// Everything the bf16 kernels read of the parameters, in ONE launch (it runs after every optimizer step, and eight
+// separate launches cost eight dispatch latencies of ~4.7 us for 15 us of work): blocks [0, nfrag) pack one fragment
+// each of the segments laid end to end (forward / density-only / backward stream of every network), the kBvecBlocks
+// blocks per network behind them write the fp32 vectors.
+__global__ __launch_bounds__(64) void repack_bf16_kernel(RepackBf16Args a) {
+  const int b = blockIdx.x;
+  if (b < a.nfrag) {
+    int sgi = 0;
+#pragma unroll
+    for (int k = 1; k < RepackBf16Args::kMaxSeg; ++k)
+      if (k < a.nseg && b >= a.seg[k].first) sgi = k;
+    const RepackBf16Args::Seg& sg = a.seg[sgi];
+    pack_frag_bf16(sg.params, sg.descs[b - sg.first], (__bf16*)sg.dst, b - sg.first, threadIdx.x);
+  } else {
+    const int net = (b - a.nfrag) / RepackBf16Args::kBvecBlocks, blk = (b - a.nfrag) % RepackBf16Args::kBvecBlocks;
+    pack_bvec_range(a.vparams[net], a.L[net], a.HT[net], a.bv[net], blk * 64 + threadIdx.x, RepackBf16Args::kBvecBlocks * 64);
   }
 }
 
@@ -236,9 +256,8 @@ hipError_t launch_pack_chunks(const float* params, const ChunkDesc* descs, int n
   hipLaunchKernelGGL(pack_chunks_kernel, dim3(n), dim3(256), 0, s, params, descs, dst);
   return hipGetLastError();
 }
-hipError_t launch_pack_frags_bf16(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_frags_bf16_kernel, dim3(n), dim3(64), 0, s, params, descs, (__bf16*)dst);
+hipError_t launch_repack_bf16(const RepackBf16Args& a, hipStream_t s) {
+  hipLaunchKernelGGL(repack_bf16_kernel, dim3(a.nfrag + a.nnets * RepackBf16Args::kBvecBlocks), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s) {
