@@ -1,15 +1,20 @@
 // f16x3_common.cuh -- machinery of the SPLIT-f16 MLP forward kernel (gfx950, v_mfma_f32_32x32x16_f16): fp32-grade
 // results at matrix-core rates.
 //
-// Every fp32 operand x is split into two halves of 11 significant bits,
-//     x  =  hi + lo / 2048 ,   hi = f16(x) ,   lo = f16((x - hi) * 2048)
-// (x - hi is exact in fp32; the scaling keeps lo a NORMAL f16 whenever hi is, so no bits are lost to f16's narrow
-// exponent range), and a product of two such numbers is taken as three MFMA terms in two fp32 accumulators:
-//     accM += w_hi . x_hi                      accL += w_hi . x_lo + w_lo . x_hi          result = accM + accL / 2048
-// The dropped term w_lo . x_lo is 2^-22 of the product and each half carries 22 bits, so one layer's output is as
-// close to the exact dot product as an fp32 fmaf chain in a different order is (measured on the golden networks:
-// max |err| 1.9e-6 against 2.0e-6 for plain fp32) -- while the three MFMAs run at the f16 rate: 2.5 PF / 3 = 833 TF
-// of fp32-grade contraction against the 157 TF of v_mfma_f32_32x32x2_f32.  Range: |x| and |w| must stay below 65504
+// Every fp32 operand is split into two halves of 11 significant bits and a product of two such numbers is taken as
+// three MFMA terms in two fp32 accumulators:
+//     weights      w = w_hi + w_lo / 2048 ,  w_hi = f16(w) ,  w_lo = f16((w - w_hi) * 2048)     (packed once, pack.hip)
+//     activations  x = x_hi + x_lo ,         x_hi = f16(x) ,  x_lo = f16(x - x_hi)              (every layer, in registers)
+//     accM += w_hi . x_hi + w_hi . x_lo           accL += w_lo . x_hi           result = accM + accL / 2048
+// (x - hi is exact in fp32.)  The scaling keeps w_lo a NORMAL f16 whenever w_hi is: the weights are small (N(0, 2/fan_in))
+// and what is lost of w_lo is multiplied by activations of O(1..10).  The activations' low halves are NOT scaled: below
+// |x| = 0.25 x_lo becomes a subnormal f16 and the pair is exact only to 2^-25 absolute instead of 2^-22 relative, but that
+// error is multiplied by a weight of O(0.1) -- emulated on a 256 x 256 layer the result is as close to the exact product
+// as with both halves scaled (rms 7.6e-8 against 7.5e-8; plain fp32 GEMM: 2.0e-7) -- and the unscaled residual is ONE
+// instruction per value (v_fma_mix{lo,hi}_f16: f16(hi * -1 + x)) where the scaled one took four.
+// The dropped term w_lo . x_lo is 2^-22 of the product, so one layer's output is as close to the exact dot product as
+// an fp32 fmaf chain in a different order is -- while the three MFMAs run at the f16 rate: 2.5 PF / 3 = 833 TF of
+// fp32-grade contraction against the 157 TF of v_mfma_f32_32x32x2_f32.  Range: |x| and |w| must stay below 65504
 // (f16 max); the network's activations are O(1..10^2).
 //
 // Structure: that of the bf16 kernels (bf16_common.cuh) -- transposed formulation, output-tile-outer loop, weight
@@ -32,7 +37,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+constexpr float kLoInv = 1.0f / 2048.0f;   // scale of the WEIGHTS' low halves (pack.hip: pack_frags_f16x3_kernel)
 constexpr int kWaves = 4;              // one per SIMD
 constexpr int kTileSamples = kWaves * 32;
 constexpr int kBlkFrags = 32;          // 1-KiB fragments per ring block = 16 (hi, lo) pairs
@@ -60,12 +65,20 @@ struct Ring {
   float* ring;
   uint32_t ring_addr;   // LDS byte address of slot 0 + lane*16
   int nblk, blk, req, req_src, wave, lane;
+  uint32_t voff;        // this lane's byte offset inside a block: wave quarter + lane * 16
   __device__ __forceinline__ void request() {
-    const char* src = stream + (size_t)req_src * kBlkBytes + wave * (kBlkBytes / kWaves) + lane * 16;
+    // one wave moves its quarter of the block with 8 LDS-DMA instructions of 1 KiB; the piece offset rides in the
+    // instruction's immediate (applied to the global AND the LDS address, 4 KiB range), so a request costs two
+    // address/M0 set-ups instead of eight
+    const char* src = stream + (size_t)req_src * kBlkBytes + voff;
     char* dst = reinterpret_cast<char*>(ring) + (req & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / kWaves);
 #pragma unroll
-    for (int p = 0; p < kDmaPieces; ++p)
-      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + p * 1024), NERFHIP_LPTR(dst + p * 1024), 16, 0, 0);
+    for (int g = 0; g < kDmaPieces / 4; ++g) {
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 3072, 0);
+    }
     asm volatile("" ::: "memory");
     ++req;
     req_src = req_src + 1 == nblk ? 0 : req_src + 1;
@@ -114,16 +127,19 @@ __device__ __forceinline__ f32x16 bias_value(BiasBuf& b) {   // call only behind
   return c;
 }
 
-// a (hi, lo) operand pair of one k-step: 8 f16 each
-struct Pair { f16x8 hi, lo; };
-// split two fp32 values into element pair i (0..3) of an operand pair
+// a (hi, lo) operand pair of one k-step: 8 f16 each, kept as 4 dwords of two
+struct Pair { u32x4 hi, lo; };
+__device__ __forceinline__ f16x8 as_f16x8(const u32x4& v) { return __builtin_bit_cast(f16x8, v); }
+// split two fp32 values into element pair i (0..3) of an operand pair: hi = f16(v), lo = f16(v - hi) (unscaled)
 __device__ __forceinline__ void split_into(Pair& p, int i, float v0, float v1) {
   const f32x2 v = {v0, v1};
-  const f16x2 h = __builtin_convertvector(v, f16x2);
-  const f32x2 r = {fmaf((float)h[0], -kLoScale, v0 * kLoScale), fmaf((float)h[1], -kLoScale, v1 * kLoScale)};
-  const f16x2 l = __builtin_convertvector(r, f16x2);
-  p.hi[2 * i] = h[0]; p.hi[2 * i + 1] = h[1];
-  p.lo[2 * i] = l[0]; p.lo[2 * i + 1] = l[1];
+  const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  uint32_t l;
+  // f16(f32(h.half) * -1 + v): the residual straight from the packed halves, one rounding
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(v0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(v1));
+  p.hi[i] = h;
+  p.lo[i] = l;
 }
 
 // ---- one layer part: OT output tiles x KS k-steps; step j = ot*KS + ks consumes fragment pair j ----------------
@@ -183,13 +199,13 @@ struct PartStep {
       if constexpr (BIAS) c0 = bias_value(bias);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { z0[r] = 0.f; if constexpr (!BIAS) c0[r] = 0.f; }
-      accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.hi, c0, 0, 0, 0);
-      accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.lo, z0, 0, 0, 0);
+      accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.hi), c0, 0, 0, 0);
+      accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, as_f16x8(b.hi), z0, 0, 0, 0);
     } else {
-      accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.hi, accM[ot & 1], 0, 0, 0);
-      accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.lo, accL[ot & 1], 0, 0, 0);
+      accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.hi), accM[ot & 1], 0, 0, 0);
+      accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, as_f16x8(b.hi), accL[ot & 1], 0, 0, 0);
     }
-    accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b.hi, accL[ot & 1], 0, 0, 0);
+    accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.lo), accM[ot & 1], 0, 0, 0);
     if constexpr (ot >= 1) EpiPieces<KS, Epi, ot - 1, ks>::run(epi, accM[(ot - 1) & 1], accL[(ot - 1) & 1]);
     if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<KS, Epi, ot, -1>::run(epi, accM[ot & 1], accL[ot & 1]);
     if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkPairs; rg.sync_point(); }

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
   rg.ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem + (uint32_t)lane * 16u;
   rg.wave = wave;
   rg.lane = lane;
+  rg.voff = (uint32_t)(wave * (kBlkBytes / kWaves) + lane * 16);
   rg.nblk = nblk;
   for (int i = tid; i < nvec; i += 64 * kWaves) vec[i] = bvec[i];
   const uint32_t vec_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)vec + (uint32_t)h * 16u;
