@@ -212,38 +212,45 @@ def main():
 
     # ---- everything below is extra reporting next to the headline numbers above; with one rank a failure in it is
     # recorded in the line instead of losing the line (with several ranks it must propagate: the others would hang)
-    render_bf16 = train_bf16 = config5 = render_pose = hbm_kernels = cpu = None
+    render_bf16 = render_f16x3 = train_bf16 = config5 = render_pose = hbm_kernels = cpu = None
     extras_error = None
     try:
-        # ---- bf16-MFMA render leg (BASELINE configs[4] arithmetic on the same frames; parity bar 1e-2 abs, tests/test_gpu_bf16.py)
-        render_bf16 = None
-        if args.dtype == "f32" and not args.no_bf16_render:
-            rb = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype="bf16")))
+        # ---- render legs on the other MFMA paths, same frames: bf16 (BASELINE configs[4] arithmetic; parity bar 1e-2 abs,
+        # tests/test_gpu_bf16.py) and split-f16 (dtype "f16x3": three f16 MFMAs per product, held to the fp32 parity
+        # tests at the fp32 tolerances, tests/test_gpu_render.py) -- reported under their own dtype labels
+        def render_leg(dt, label, peak_tf, peak_note):
+            rb = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype=dt)))
             rb.set_stream(stream)
             rb.set_params(trainer.get_params())
             rb.render_dev(ro, rd, bd, rd, n_frame, out)
             torch.cuda.synchronize(); barrier()
             rb.set_profiling(True)
-            t0 = time.perf_counter()
+            t0_ = time.perf_counter()
             for _ in range(args.render_frames):
                 rb.render_dev(ro, rd, bd, rd, n_frame, out)
             torch.cuda.synchronize(); barrier()
-            dtb = time.perf_counter() - t0
+            dtb = time.perf_counter() - t0_
             bprof = rb.get_profile()
             if world > 1:
-                t = torch.tensor([dtb], device="cuda", dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dtb = float(t.item())
+                t_ = torch.tensor([dtb], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                dtb = float(t_.item())
             b_ach = bprof["mlp_fwd_flop"] / max(bprof["mlp_fwd_ms"], 1e-9) / 1e9
-            render_bf16 = {"metric": "rays/sec (render, bf16 MFMA)", "value": round(world * n_frame * args.render_frames / dtb, 1),
-                           "unit": "rays/s", "dtype": "bf16", "ms_per_frame": round(1e3 * dtb / args.render_frames, 3),
-                           "roofline": {"kernel": "mlp_fwd_bf16", "bound": "mfma", "achieved": round(b_ach, 2),
-                                        "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                                        "frac": round(b_ach / PEAK_TFLOPS["bf16"], 4)},
-                           "hbm_kernels_ms_per_frame": {"composite": round(bprof["composite_ms"] / args.render_frames, 4),
-                                                        "sampling": round(bprof["sampling_ms"] / args.render_frames, 4)}}
             rb.close()
-            note("bf16 render leg done")
+            note(f"{dt} render leg done")
+            return {"metric": f"rays/sec (render, {label})", "value": round(world * n_frame * args.render_frames / dtb, 1),
+                    "unit": "rays/s", "dtype": dt, "ms_per_frame": round(1e3 * dtb / args.render_frames, 3),
+                    "roofline": {"kernel": f"mlp_fwd_{dt}", "bound": "mfma", "achieved": round(b_ach, 2), "peak": peak_tf,
+                                 "unit": "TFLOP/s", "frac": round(b_ach / peak_tf, 4), "peak_note": peak_note},
+                    "hbm_kernels_ms_per_frame": {"composite": round(bprof["composite_ms"] / args.render_frames, 4),
+                                                 "sampling": round(bprof["sampling_ms"] / args.render_frames, 4)}}
+
+        render_bf16 = render_f16x3 = None
+        if args.dtype == "f32" and not args.no_bf16_render:
+            render_bf16 = render_leg("bf16", "bf16 MFMA", PEAK_TFLOPS["bf16"], "dense bf16 MFMA peak")
+            render_f16x3 = render_leg("f16x3", "split-f16 MFMA, fp32-grade", round(PEAK_TFLOPS["bf16"] / 3.0, 1),
+                                      "dense f16 MFMA peak / 3 (three MFMAs per fp32-grade product); achieved counts the "
+                                      "ALGORITHMIC fp32 FLOPs")
 
         # ---- bf16-MFMA training legs: the same batch (configs[3] arithmetic in bf16), and BASELINE configs[4]:
         # 1024x1024 forward-facing scene, NDC rays (llff.scala:96-132), 64 + 256 samples per ray
@@ -357,6 +364,11 @@ def main():
             rb2.set_params(trainer.get_params())
             render_pose["bf16"] = pose_frame(rb2, 3)
             rb2.close()
+            rb3 = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=n_frame, dtype="f16x3")))
+            rb3.set_stream(stream)
+            rb3.set_params(trainer.get_params())
+            render_pose["f16x3"] = pose_frame(rb3, 2)
+            rb3.close()
 
         # ---- HBM-bound kernels on one frame's fine pass (160 000 rays x 192 samples): achieved GB/s on algorithmic bytes
         # (compositing fwd 24 B/sample, bwd 40 B/sample; resampling 8 B per coarse + 4 B per fine sample)
@@ -419,7 +431,8 @@ def main():
                 # samples/s counts network evaluations: 64 coarse + 192 fine per ray (the 192 of samples_per_ray are the
                 # compositing samples of the fine pass)
                 "samples_per_s": round(train_rays_s * 256, 1),
-                "roofline": roofline, "render": render, "render_bf16": render_bf16, "train_bf16": train_bf16,
+                "roofline": roofline, "render": render, "render_bf16": render_bf16, "render_f16x3": render_f16x3,
+                "train_bf16": train_bf16,
                 "config5_bf16": config5, "render_pose_800": render_pose, "hbm_kernels": hbm_kernels,
                 "cpu_baseline": cpu, "extras_error": extras_error}
         print(json.dumps(line))
