@@ -369,7 +369,7 @@ int repack(nerfhip* h) {
     if (h->cfg.dtype == NERFHIP_F16X3) {   // + the render kernel's pair streams (training stays on the fp32 kernels)
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->stream));
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, h->stream));
-      HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, h->stream));
+      HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, 64.0f, h->stream));
     }
   }
   h->packed = true;

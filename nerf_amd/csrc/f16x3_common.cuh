@@ -1,21 +1,23 @@
 // f16x3_common.cuh -- machinery of the SPLIT-f16 MLP forward kernel (gfx950, v_mfma_f32_32x32x16_f16): fp32-grade
 // results at matrix-core rates.
 //
-// Every fp32 operand is split into two halves of 11 significant bits and a product of two such numbers is taken as
-// three MFMA terms in two fp32 accumulators:
-//     weights      w = w_hi + w_lo / 2048 ,  w_hi = f16(w) ,  w_lo = f16((w - w_hi) * 2048)     (packed once, pack.hip)
-//     activations  x = x_hi + x_lo ,         x_hi = f16(x) ,  x_lo = f16(x - x_hi)              (every layer, in registers)
-//     accM += w_hi . x_hi + w_hi . x_lo           accL += w_lo . x_hi           result = accM + accL / 2048
-// (x - hi is exact in fp32.)  The scaling keeps w_lo a NORMAL f16 whenever w_hi is: the weights are small (N(0, 2/fan_in))
-// and what is lost of w_lo is multiplied by activations of O(1..10).  The activations' low halves are NOT scaled: below
-// |x| = 0.25 x_lo becomes a subnormal f16 and the pair is exact only to 2^-25 absolute instead of 2^-22 relative, but that
-// error is multiplied by a weight of O(0.1) -- emulated on a 256 x 256 layer the result is as close to the exact product
-// as with both halves scaled (rms 7.6e-8 against 7.5e-8; plain fp32 GEMM: 2.0e-7) -- and the unscaled residual is ONE
-// instruction per value (v_fma_mix{lo,hi}_f16: f16(hi * -1 + x)) where the scaled one took four.
-// The dropped term w_lo . x_lo is 2^-22 of the product, so one layer's output is as close to the exact dot product as
-// an fp32 fmaf chain in a different order is -- while the three MFMAs run at the f16 rate: 2.5 PF / 3 = 833 TF of
-// fp32-grade contraction against the 157 TF of v_mfma_f32_32x32x2_f32.  Range: |x| and |w| must stay below 65504
-// (f16 max); the network's activations are O(1..10^2).
+// Every fp32 operand is split into two f16 halves of 11 significant bits each and a product of two such numbers is
+// taken as three MFMA terms in ONE fp32 accumulator:
+//     weights      64 w = w_hi + w_lo ,  w_hi = f16(64 w) ,  w_lo = f16(64 w - w_hi)     (packed once, pack.hip)
+//     activations     x = x_hi + x_lo ,  x_hi = f16(x) ,     x_lo = f16(x - x_hi)        (every layer, in registers)
+//     acc += w_hi . x_hi + w_hi . x_lo + w_lo . x_hi          acc = 64 (W x + b)   (the bias enters as 64 b)
+// (v - f16(v) is exact in fp32, so each half pair is exact up to the rounding of its low half.)  Why the weights carry
+// a factor 64: a low half is an UNSCALED residual, 2^-11 of its high half, and f16 has only 5 exponent bits -- below
+// |v| = 0.25 the residual is a subnormal f16 and the pair is exact to 2^-25 absolute instead of 2^-22 relative.  For
+// the activations that does not matter (the error is multiplied by a weight of O(0.1)); for the weights, N(0, 2/fan_in)
+// and multiplied by activations of O(1..10), it would, so they are stored 64 times larger: exact pairs down to
+// |w| = 0.004, range |w| < 1023.  The factor is taken out again where the accumulator is read -- inside the
+// v_fma_mix{lo,hi}_f16 that make the next layer's halves (f16(acc/64) and f16(acc/64 - hi): two instructions per
+// value, no separate conversion, scaling or merge).  The dropped term w_lo . x_lo is 2^-22 of the product.  Emulated
+// on a 256 x 256 layer (products exact, one fp32 rounding of the accumulator per MFMA) the result is closer to the
+// exact product than a sequential fp32 fmaf chain is (rms 1.5e-7 against 2.0e-7), for weights 10 x smaller or 5 x
+// larger alike -- while the three MFMAs run at the f16 rate: 2.5 PF / 3 = 833 TF of fp32-grade contraction against
+// the 157 TF of v_mfma_f32_32x32x2_f32.  Range: |x| < 65504 and |w| < 1023.
 //
 // Structure: that of the bf16 kernels (bf16_common.cuh) -- transposed formulation, output-tile-outer loop, weight
 // fragments through a 4 x 32 KiB LDS ring fed by LDS-DMA, asm ds_read_b128 with counted lgkmcnt, the epilogue of
@@ -25,6 +27,9 @@
 // workgroup.
 #pragma once
 #include "mlp_common.cuh"
+#ifndef NH_EXP_NODMA
+#define NH_EXP_NODMA 0
+#endif
 #ifndef NH_X3_PD
 #define NH_X3_PD 2
 #endif
@@ -37,7 +42,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float kLoInv = 1.0f / 2048.0f;   // scale of the WEIGHTS' low halves (pack.hip: pack_frags_f16x3_kernel)
+constexpr float kWScale = 64.0f, kWInv = 1.0f / 64.0f;   // factor on the packed weights and biases (pack.hip)
 constexpr int kWaves = 4;              // one per SIMD
 constexpr int kTileSamples = kWaves * 32;
 constexpr int kBlkFrags = 32;          // 1-KiB fragments per ring block = 16 (hi, lo) pairs
@@ -73,7 +78,7 @@ struct Ring {
     const char* src = stream + (size_t)req_src * kBlkBytes + voff;
     char* dst = reinterpret_cast<char*>(ring) + (req & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / kWaves);
 #pragma unroll
-    for (int g = 0; g < kDmaPieces / 4; ++g) {
+    for (int g = 0; g < ((NH_EXP_NODMA && req >= kRing) ? 0 : kDmaPieces / 4); ++g) {
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 1024, 0);
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 2048, 0);
@@ -87,6 +92,7 @@ struct Ring {
     blk = 0; req = 0; req_src = 0;
     asm volatile("" ::: "memory");
     request(); request(); request();
+    if (NH_EXP_NODMA) { request(); req = kRing; }
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kDmaPieces) : "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -130,7 +136,7 @@ __device__ __forceinline__ f32x16 bias_value(BiasBuf& b) {   // call only behind
 // a (hi, lo) operand pair of one k-step: 8 f16 each, kept as 4 dwords of two
 struct Pair { u32x4 hi, lo; };
 __device__ __forceinline__ f16x8 as_f16x8(const u32x4& v) { return __builtin_bit_cast(f16x8, v); }
-// split two fp32 values into element pair i (0..3) of an operand pair: hi = f16(v), lo = f16(v - hi) (unscaled)
+// split two fp32 values into element pair i (0..3) of an operand pair: hi = f16(v), lo = f16(v - hi)
 __device__ __forceinline__ void split_into(Pair& p, int i, float v0, float v1) {
   const f32x2 v = {v0, v1};
   const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
@@ -141,10 +147,21 @@ __device__ __forceinline__ void split_into(Pair& p, int i, float v0, float v1) {
   p.hi[i] = h;
   p.lo[i] = l;
 }
+// the same for two accumulator values that still carry the weights' factor: x = a / 64 (exact), hi = f16(x),
+// lo = f16(x - hi), each half one fused multiply-add that rounds once to f16
+__device__ __forceinline__ void split_scaled_into(Pair& p, int i, float a0, float a1) {
+  uint32_t h, l;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a0), "s"(kWInv));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(a1), "s"(kWInv));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "s"(kWInv), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "s"(kWInv), "v"(h));
+  p.hi[i] = h;
+  p.lo[i] = l;
+}
 
 // ---- one layer part: OT output tiles x KS k-steps; step j = ot*KS + ks consumes fragment pair j ----------------
 // BSel:  template <int KS_IDX> const Pair& b() const            B operand pair of k-step KS_IDX
-// Epi:   static constexpr int kPieces;  template <int OT_IDX, int P> void piece(const f32x16& accM, const f32x16& accL)
+// Epi:   static constexpr int kPieces;  template <int OT_IDX, int P> void piece(const f32x16& acc)   (acc = 64 x the tile)
 //        the epilogue of a finished output tile, cut into kPieces pieces spread over the k-steps of the NEXT tile
 template <int KS, int OT, bool BIAS = true>
 struct PartSched {
@@ -169,10 +186,10 @@ template <int KS, int NP>
 constexpr int piece_offset(int p) { return (p * KS) / NP; }
 template <int KS, class Epi, int OT_IDX, int OFF, int P = 0>
 struct EpiPieces {   // runs the pieces of tile OT_IDX scheduled at k-step offset OFF (OFF < 0: all)
-  static __device__ __forceinline__ void run(Epi& epi, const f32x16& aM, const f32x16& aL) {
+  static __device__ __forceinline__ void run(Epi& epi, const f32x16& a) {
     if constexpr (P < Epi::kPieces) {
-      if constexpr (OFF < 0 || piece_offset<KS, Epi::kPieces>(P) == OFF) epi.template piece<OT_IDX, P>(aM, aL);
-      EpiPieces<KS, Epi, OT_IDX, OFF, P + 1>::run(epi, aM, aL);
+      if constexpr (OFF < 0 || piece_offset<KS, Epi::kPieces>(P) == OFF) epi.template piece<OT_IDX, P>(a);
+      EpiPieces<KS, Epi, OT_IDX, OFF, P + 1>::run(epi, a);
     }
   }
 };
@@ -181,7 +198,7 @@ template <int KS, int OT, class BSel, class Epi, bool BIAS, int J>
 struct PartStep {
   using S = PartSched<KS, OT, BIAS>;
   static __device__ __forceinline__ void run(Ring& rg, int blk0, uint32_t bias_addr, f16x8 (&fr)[kPD + 1][2], BiasBuf& bias,
-                                             f32x16 (&accM)[2], f32x16 (&accL)[2], const BSel& bsel, Epi& epi) {
+                                             f32x16 (&acc)[2], const BSel& bsel, Epi& epi) {
     constexpr int ot = J / KS, ks = J % KS;
     if constexpr (J + kPD < S::NF) {
       constexpr int jj = J + kPD;
@@ -195,21 +212,22 @@ struct PartStep {
     const f16x8& wl = fr[J % (kPD + 1)][1];
     const Pair& b = bsel.template b<ks>();
     if constexpr (ks == 0) {
-      f32x16 c0, z0;
+      f32x16 c0;
       if constexpr (BIAS) c0 = bias_value(bias);
+      else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { z0[r] = 0.f; if constexpr (!BIAS) c0[r] = 0.f; }
-      accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.hi), c0, 0, 0, 0);
-      accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, as_f16x8(b.hi), z0, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+      }
+      acc[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.hi), c0, 0, 0, 0);
     } else {
-      accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.hi), accM[ot & 1], 0, 0, 0);
-      accL[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, as_f16x8(b.hi), accL[ot & 1], 0, 0, 0);
+      acc[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.hi), acc[ot & 1], 0, 0, 0);
     }
-    accM[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.lo), accM[ot & 1], 0, 0, 0);
-    if constexpr (ot >= 1) EpiPieces<KS, Epi, ot - 1, ks>::run(epi, accM[(ot - 1) & 1], accL[(ot - 1) & 1]);
-    if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<KS, Epi, ot, -1>::run(epi, accM[ot & 1], accL[ot & 1]);
+    acc[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, as_f16x8(b.lo), acc[ot & 1], 0, 0, 0);
+    acc[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, as_f16x8(b.hi), acc[ot & 1], 0, 0, 0);
+    if constexpr (ot >= 1) EpiPieces<KS, Epi, ot - 1, ks>::run(epi, acc[(ot - 1) & 1]);
+    if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<KS, Epi, ot, -1>::run(epi, acc[ot & 1]);
     if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkPairs; rg.sync_point(); }
-    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, BIAS, J + 1>::run(rg, blk0, bias_addr, fr, bias, accM, accL, bsel, epi);
+    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, BIAS, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   }
 };
 
@@ -230,11 +248,11 @@ __device__ __forceinline__ void run_part(Ring& rg, uint32_t bias_addr, const BSe
   const int blk0 = rg.blk;
   f16x8 fr[kPD + 1][2];
   BiasBuf bias;
-  f32x16 accM[2], accL[2];
+  f32x16 acc[2];
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (BIAS) bias_read<0>(bias, bias_addr);
   prime_pairs<S::NF, 0>(fr, rg.slot_addr(blk0));
-  PartStep<KS, OT, BSel, Epi, BIAS, 0>::run(rg, blk0, bias_addr, fr, bias, accM, accL, bsel, epi);
+  PartStep<KS, OT, BSel, Epi, BIAS, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   wait_lgkm_n<0>();
   __builtin_amdgcn_sched_barrier(0);
   rg.blk = blk0 + (S::NF + kBlkPairs - 1) / kBlkPairs;

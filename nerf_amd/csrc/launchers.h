@@ -45,7 +45,8 @@ hipError_t launch_mlp_bwd_f32(const NetArgs& net, const float* d_sigma, const fl
                               int64_t M, int S, int has_rgb, const ActStore& st, hipStream_t stream);
 
 // bf16 path
-hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s);
+// scale: factor on every entry (1; 64 for the split-f16 kernel, whose accumulators carry the weights' factor)
+hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, float scale, hipStream_t s);
 // all bf16 streams and vectors of up to two networks in one launch (pack.hip: repack_bf16_kernel)
 struct RepackBf16Args {
   static constexpr int kMaxSeg = 6, kBvecBlocks = 16;

@@ -294,18 +294,62 @@ __device__ __forceinline__ void load_rows(f32x16 (&acc)[NT], const float* v, int
 }
 
 // One value of positionCode(x, L) (nerfCoreBlock.scala:127-136): index e of [x, sin(x), cos(x), sin(2x) ...]
-__device__ __forceinline__ float code_value(float px, float py, float pz, int e, int E) {
-  if (e >= E) return 0.f;
-  if (e < 3) return e == 0 ? px : (e == 1 ? py : pz);
-  const int t = e - 3;
-  const int f = t / 6;
-  const int rem = t - 6 * f;
-  const int c = rem >= 3 ? rem - 3 : rem;
-  const float x = c == 0 ? px : (c == 1 ? py : pz);
-  const float a = x * (float)(1 << f);   // input.mul(1 << i)
-  float s, co;
-  sincosf(a, &s, &co);
-  return rem >= 3 ? co : s;
+// sin(a) or cos(a) to ~1.5 ulp of a value near 1 (absolute error <= 1e-7, exact at a = 0) for |a| <= kTrigMax:
+// Cody-Waite reduction by pi/2 in three fused steps (the first is exact: a - n fl(pi/2) is representable), cephes'
+// single-precision kernels on [-pi/4, pi/4], cos(a) = sin(a + pi/2).  About 20 instructions; libm's sinf/cosf carry
+// a Payne-Hanek reduction for huge arguments that the compiler evaluates for EVERY value (selects, not branches):
+// 235 instructions per value, 20 000 cycles per 128-sample tile for the 32 values a lane encodes.
+constexpr float kTrigMax = 8192.0f;
+__device__ __forceinline__ float sin_or_cos_reduced(float a, int want_cos) {   // want_cos: 0 | 1
+  const float n = __builtin_rintf(a * 0.636619772f);
+  float r = fmaf(n, -1.5707963705062866f, a);
+  r = fmaf(n, 4.371138828673793e-08f, r);
+  r = fmaf(n, 1.7151245100058819e-15f, r);
+  const int q = (int)n + want_cos;
+  const float z = r * r;
+  const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  const float sn = fmaf(ps * z, r, r);
+  const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  const float cs = fmaf(pc, z * z, fmaf(-0.5f, z, 1.0f));
+  const float v = (q & 1) ? cs : sn;
+  return (q & 2) ? -v : v;
+}
+
+// Element e of positionCode(p, L) (nerfCoreBlock.scala:127-136): [p, sin(p 2^0), cos(p 2^0), ..., cos(p 2^(L-1))], each
+// block 3 wide.  The fused kernels give lane half h the elements e = e0 + 4 h with e0 known at compile time (after
+// unrolling), so what an element is -- coordinate, frequency, sin or cos -- is a choice between two constants and both
+// lane halves run ONE instruction stream (a divergent `if (h)` around two specialised streams costs both).
+// RED: every argument of the wave's samples is within kTrigMax (trig_reduced), else libm's functions.
+struct CodeInfo { int coord; float scale; int want_cos; bool raw; };
+__host__ __device__ constexpr CodeInfo code_info(int e) {
+  if (e < 3) return CodeInfo{e, 1.f, 0, true};
+  const int t = e - 3, f = t / 6, rem = t - 6 * f;
+  return CodeInfo{rem >= 3 ? rem - 3 : rem, (float)(1 << f), rem >= 3 ? 1 : 0, false};   // input.mul(1 << i)
+}
+template <bool RED>
+__device__ __forceinline__ float code_value_h(float px, float py, float pz, int e0, int h, int E) {
+  const CodeInfo i0 = code_info(e0), i1 = code_info(e0 + 4);
+  const float x0 = i0.coord == 0 ? px : (i0.coord == 1 ? py : pz);
+  const float x1 = i1.coord == 0 ? px : (i1.coord == 1 ? py : pz);
+  const float x = h ? x1 : x0;
+  const float a = x * (h ? i1.scale : i0.scale);
+  const int wc = h ? i1.want_cos : i0.want_cos;
+  float v;
+  if constexpr (RED) {
+    v = sin_or_cos_reduced(a, wc);
+  } else {
+    float sn, cs;
+    sincosf(a, &sn, &cs);
+    v = wc ? cs : sn;
+  }
+  if (i0.raw) v = h ? v : x0;            // e0 < 3: the coordinate itself (e0 + 4 never is)
+  return e0 + 4 * h < E ? v : 0.f;       // zero padding up to 64 rows
+}
+// wave-uniform: all encoding arguments p * 2^(L-1) of the wave's samples are within the reduced routine's range (E = 3 + 6 L)
+__device__ __forceinline__ bool trig_reduced(float px, float py, float pz, int E) {
+  const float top = (float)(1 << ((E - 3) / 6 > 0 ? (E - 3) / 6 - 1 : 0));
+  const bool ok = fmaxf(fmaxf(fabsf(px), fabsf(py)), fabsf(pz)) * top <= kTrigMax;   // false for NaN too
+  return __builtin_amdgcn_ballot_w64(!ok) == 0;
 }
 
 }  // namespace nh

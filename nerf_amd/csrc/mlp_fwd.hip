@@ -53,10 +53,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   // Rows past M repeat sample M-1 (finite values); their gradients are zero in the backward pass, so the
   // stored activations of those columns never contribute to a weight gradient.
   f32x16 enc[2];
+  if (trig_reduced(px, py, pz, net.E)) {   // wave-uniform: the usual case, sin/cos by the short routine (mlp_common.cuh)
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) enc[t][r] = code_value(px, py, pz, tile_row(t, r, h), net.E);
+      for (int r = 0; r < 16; ++r) enc[t][r] = code_value_h<true>(px, py, pz, tile_row(t, r, 0), h, net.E);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) enc[t][r] = code_value_h<false>(px, py, pz, tile_row(t, r, 0), h, net.E);
+  }
   __syncthreads();
 
   f32x16 act[WT], acc[WT];

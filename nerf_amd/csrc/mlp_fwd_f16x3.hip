@@ -1,12 +1,19 @@
 // mlp_fwd_f16x3.hip -- fused positional-encoding + density/colour MLP forward with SPLIT-f16 MFMA operands (gfx950),
 // inference: the function of mlp_fwd.hip (reference nerf/nerfCoreBlock.scala:17-112) to fp32 accuracy at matrix-core
-// rates (f16x3_common.cuh: x = hi + lo/2048, three v_mfma_f32_32x32x16_f16 per product, two fp32 accumulators).
+// rates (f16x3_common.cuh: x = hi + lo, three v_mfma_f32_32x32x16_f16 per product into one fp32 accumulator that
+// carries the factor 64 of the packed weights).
 // Held to the SAME parity bars as the fp32 kernels (tests: every fp32 render test also runs with dtype f16x3).
-// Positions, the encoding's sin/cos (accurate sinf/cosf, not the hardware approximations of the bf16 path), biases,
+// Positions, the encoding's sin/cos (accurate ones, mlp_common.cuh, not the hardware approximations of the bf16 path), biases,
 // the per-ray view-direction branch and all accumulators are fp32.
 // One wave = 32 samples x all features, one wave per SIMD (512 registers), workgroup = 4 waves = 128 samples,
 // persistent (one per CU).  Stream layout = that of the bf16 kernel with every fragment replaced by its (hi, lo) pair
 // and every part padded to whole 16-pair blocks (api.hip: build_bf16_streams(pad 16) + pack.hip: pack_frags_f16x3).
+#ifndef NH_EXP_NODIR
+#define NH_EXP_NODIR 0
+#endif
+#ifndef NH_EXP_STAMP
+#define NH_EXP_STAMP 0
+#endif
 #include "f16x3_common.cuh"
 #include <algorithm>
 #include "launchers.h"
@@ -36,24 +43,25 @@ struct SelHid {
   template <int KS_IDX> __device__ __forceinline__ const Pair& b() const { return a.v[KS_IDX / 2][KS_IDX % 2]; }
 };
 
-// accM + accL/2048 of accumulator register R_
-template <int R_>
-__device__ __forceinline__ float merged(const f32x16& aM, const f32x16& aL) { return fmaf(aL[R_], kLoInv, aM[R_]); }
+// In every epilogue `a` is the finished accumulator tile = 64 x (W x + b) (f16x3_common.cuh: kWScale).
+
+// relu on the integer bits (negative floats and -0 are negative integers): one v_max_i32 where fmaxf on a value that
+// comes out of an asm-free register costs a canonicalising v_max_f32 as well
+__device__ __forceinline__ float relu_bits(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
 
 template <int WT>
 struct EpiTrunk {   // relu + split -> B operand pairs of the next layer; piece P = registers 2P, 2P+1 of the tile
   ActRegs<WT>& out;
   static constexpr int kPieces = 8;
-  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& aM, const f32x16& aL) {
-    const float v0 = fmaxf(merged<2 * P>(aM, aL), 0.f), v1 = fmaxf(merged<2 * P + 1>(aM, aL), 0.f);
-    split_into(out.v[OT_IDX][P / 4], P % 4, v0, v1);
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
+    split_scaled_into(out.v[OT_IDX][P / 4], P % 4, relu_bits(a[2 * P]), relu_bits(a[2 * P + 1]));
   }
 };
 struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
   float* sigma; int m; bool valid; int h;
   static constexpr int kPieces = 1;
-  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& aM, const f32x16& aL) {
-    if (valid && h == 0) sigma[m] = merged<0>(aM, aL);
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
+    if (valid && h == 0) sigma[m] = a[0] * kWInv;
   }
 };
 template <int HT, int MODE>
@@ -61,17 +69,20 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
   ActRegs<HT>& hid; float (&c)[3];
   const float* dirfeat; int ray; int m; bool valid; float* sigma; int h;
   static constexpr int kPieces = 8;
-  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& aM, const f32x16& aL) {
-    const float a0 = merged<2 * P>(aM, aL), a1 = merged<2 * P + 1>(aM, aL);
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
     if constexpr (OT_IDX == HT) {
       if constexpr (P == 0)
-        if (valid && h == 0) sigma[m] = a0;
+        if (valid && h == 0) sigma[m] = a[0] * kWInv;
     } else if constexpr (MODE == 1) {
       // add().relu() (nerfCoreBlock.scala:67): + (Wd.enc(dir) + bd + bf) of the sample's ray, fp32; registers 2P, 2P+1
       // hold features 32 OT + 8 (P/2) + 2 (P%2) + 4h + {0, 1}
       const float* df = dirfeat + (int64_t)ray * (32 * HT) + 32 * OT_IDX + 8 * (P / 2) + 2 * (P % 2) + 4 * h;
+#if NH_EXP_NODIR
+      const f32x2 d = {0.1f, 0.2f}; (void)df;
+#else
       const f32x2 d = *reinterpret_cast<const f32x2*>(df);
-      split_into(hid.v[OT_IDX][P / 4], P % 4, fmaxf(a0 + d[0], 0.f), fmaxf(a1 + d[1], 0.f));
+#endif
+      split_into(hid.v[OT_IDX][P / 4], P % 4, fmaxf(fmaf(a[2 * P], kWInv, d[0]), 0.f), fmaxf(fmaf(a[2 * P + 1], kWInv, d[1]), 0.f));
     } else if constexpr (MODE == 2) {
       // reshape(...,9,3).mul(SH).sum(-2) (:55): c[k] = sum_j q[3j+k] * Y_j(dir); rows 0..26 of tile 0
       const float* Y = dirfeat + (int64_t)ray * 12;
@@ -80,14 +91,14 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
         const int row = tile_row(0, 2 * P + i, h);
         if (row < 27) {
           const int j = row / 3, k = row - 3 * j;
-          const float v = (i == 0 ? a0 : a1) * Y[j];
+          const float v = (a[2 * P + i] * kWInv) * Y[j];
           c[0] += k == 0 ? v : 0.f; c[1] += k == 1 ? v : 0.f; c[2] += k == 2 ? v : 0.f;
         }
       }
     } else {
       if (h == 0) {
-        if constexpr (P == 0) { c[0] = a0; c[1] = a1; }
-        if constexpr (P == 1) c[2] = a0;
+        if constexpr (P == 0) { c[0] = a[0] * kWInv; c[1] = a[1] * kWInv; }
+        if constexpr (P == 1) c[2] = a[2] * kWInv;
       }
     }
   }
@@ -95,25 +106,25 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
 struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
   float (&c)[3]; int h;
   static constexpr int kPieces = 2;
-  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& aM, const f32x16& aL) {
+  template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
     if (h == 0) {
-      if constexpr (P == 0) { c[0] = merged<0>(aM, aL); c[1] = merged<1>(aM, aL); }
-      if constexpr (P == 1) c[2] = merged<2>(aM, aL);
+      if constexpr (P == 0) { c[0] = a[0] * kWInv; c[1] = a[1] * kWInv; }
+      if constexpr (P == 1) c[2] = a[2] * kWInv;
     }
   }
 };
 
 // positionCode (nerfCoreBlock.scala:127-136) of this lane's 32 of the 64 (padded) features, split into operand pairs
-template <int H>
-__device__ __forceinline__ void encode_half(ActRegs<2>& enc, float px, float py, float pz, int E) {
+template <bool RED>
+__device__ __forceinline__ void encode(ActRegs<2>& enc, float px, float py, float pz, int E, int h) {
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        split_into(enc.v[kt][s], i, code_value(px, py, pz, 32 * kt + feature(s, H, 2 * i), E),
-                   code_value(px, py, pz, 32 * kt + feature(s, H, 2 * i + 1), E));
+        split_into(enc.v[kt][s], i, code_value_h<RED>(px, py, pz, 32 * kt + feature(s, 0, 2 * i), h, E),
+                   code_value_h<RED>(px, py, pz, 32 * kt + feature(s, 0, 2 * i + 1), h, E));
 }
 
 template <int WT, int MODE>
@@ -149,7 +160,14 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
   __syncthreads();   // vectors visible
   rg.start();
 
+#if NH_EXP_STAMP
+  uint64_t st[16]; int it = 0;
+#define STAMP(i) do { if (it == 3) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i)
+#endif
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    STAMP(0);
     const int m = tile * kTileSamples + wave * 32 + li;   // host guarantees M < 2^31
     const bool valid = m < (int)M;
     const int mc = valid ? m : (int)M - 1;
@@ -162,14 +180,16 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     // the encoding is computed once per sample and kept (32 registers) for the skip layers: its sin/cos are the
     // accurate ones, far too expensive to recompute
     ActRegs<2> enc;
-    if (h == 0) encode_half<0>(enc, px, py, pz, net.E);
-    else encode_half<1>(enc, px, py, pz, net.E);
+    if (trig_reduced(px, py, pz, net.E)) encode<true>(enc, px, py, pz, net.E, h);   // wave-uniform: the usual case
+    else encode<false>(enc, px, py, pz, net.E, h);
 
+    STAMP(1);
     ActRegs<WT> act, nxt;
     {
       EpiTrunk<WT> epi{act};
       run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
     }
+    STAMP(2);
     auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) {
       EpiTrunk<WT> epi{out};
       const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
@@ -179,7 +199,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     int l = 1;
     for (; l + 1 < D; l += 2) {
       layer(l, act, nxt);
+      STAMP(2 + l);
       layer(l + 1, nxt, act);
+      STAMP(3 + l);
     }
     if (l < D) {
       layer(l, act, nxt);
@@ -197,7 +219,9 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     ActRegs<HT> hid;
     float c[3] = {0.f, 0.f, 0.f};
     EpiHead<HT, MODE> epih{hid, c, dirfeat, ray, m, valid, sigma, h};
+    STAMP(10);
     run_part<2 * WT, HT + 1>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
+    STAMP(11);
     if constexpr (MODE == 1) {
       // colour output layer: Linear(3) over the H2 hidden features, as one MFMA tile (rows 0..2)
       EpiColour epic{c, h};
@@ -205,8 +229,15 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     } else if constexpr (MODE == 2) {
       c[0] += __shfl_xor(c[0], 32); c[1] += __shfl_xor(c[1], 32); c[2] += __shfl_xor(c[2], 32);
     }
+    STAMP(12);
+#if NH_EXP_STAMP
+    ++it;
+#endif
     if (valid && h == 0) { craw[(int64_t)m * 3 + 0] = c[0]; craw[(int64_t)m * 3 + 1] = c[1]; craw[(int64_t)m * 3 + 2] = c[2]; }
   }   // tile loop
+#if NH_EXP_STAMP
+  if (blockIdx.x == 5 && tid == 0) for (int i = 0; i < 13; ++i) reinterpret_cast<uint64_t*>(craw)[i] = st[i];
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 

@@ -43,8 +43,8 @@ __device__ __forceinline__ void pack_frag_bf16(const float* __restrict__ params,
     o[e] = (__bf16)v;
   }
 }
-// split-f16 weight streams (f16x3_common.cuh): descriptor i -> fragment 2i = hi = f16(w), fragment 2i+1 = lo =
-// f16((w - hi) * 2048); same lane / element order as the bf16 fragments
+// split-f16 weight streams (f16x3_common.cuh): descriptor i -> fragment 2i = hi = f16(64 w), fragment 2i+1 = lo =
+// f16(64 w - hi); same lane / element order as the bf16 fragments
 __global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __restrict__ params,
                                                               const FragDesc* __restrict__ descs,
                                                               _Float16* __restrict__ dst) {
@@ -60,16 +60,17 @@ __global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __res
     float v = 0.f;
     if (d.src_off >= 0 && row < d.nrows && f < d.kvalid)
       v = d.transposed ? src[(int64_t)(d.col0 + f) * d.ld + row] : src[(int64_t)row * d.ld + d.col0 + f];
-    const _Float16 hi = (_Float16)v;
+    const float vs = __fmul_rn(v, 64.0f);   // exact
+    const _Float16 hi = (_Float16)vs;
     oh[e] = hi;
-    ol[e] = (_Float16)(__fmul_rn(__fsub_rn(v, (float)hi), 2048.0f));
+    ol[e] = (_Float16)(__fsub_rn(vs, (float)hi));
   }
 }
 
 // bf16 path vectors (fp32): [D*W] trunk biases | [(HT+1)*32] head accumulator init (mode 1: zero, the per-ray
 // direction vector carries bf + bd; else bf; tile HT: b_sigma at row 0) | [32] colour bias (mode 1)
 __device__ __forceinline__ void pack_bvec_range(const float* __restrict__ params, const NetLayout& L, int HT,
-                                                float* __restrict__ bv, int first, int stride) {
+                                                float* __restrict__ bv, int first, int stride, float scale = 1.0f) {
   const int W = L.W, D = L.D;
   const int total = D * W + (HT + 1) * 32 + 32;
   for (int idx = first; idx < total; idx += stride) {
@@ -85,11 +86,11 @@ __device__ __forceinline__ void pack_bvec_range(const float* __restrict__ params
       const int j = idx - (D * W + (HT + 1) * 32);
       if (L.mode == 1 && j < 3) v = params[L.bc_off + j];
     }
-    bv[idx] = v;
+    bv[idx] = v * scale;
   }
 }
-__global__ void pack_bvec_kernel(const float* __restrict__ params, NetLayout L, int HT, float* __restrict__ bv) {
-  pack_bvec_range(params, L, HT, bv, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+__global__ void pack_bvec_kernel(const float* __restrict__ params, NetLayout L, int HT, float* __restrict__ bv, float scale) {
+  pack_bvec_range(params, L, HT, bv, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, scale);
 }
 
 // Everything the bf16 kernels read of the parameters, in ONE launch (it runs after every optimizer step, and eight
@@ -265,8 +266,8 @@ hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, i
   hipLaunchKernelGGL(pack_frags_f16x3_kernel, dim3(n), dim3(64), 0, s, params, descs, (_Float16*)dst);
   return hipGetLastError();
 }
-hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, hipStream_t s) {
-  hipLaunchKernelGGL(pack_bvec_kernel, dim3(16), dim3(256), 0, s, params, L, HT, bv);
+hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(pack_bvec_kernel, dim3(16), dim3(256), 0, s, params, L, HT, bv, scale);
   return hipGetLastError();
 }
 hipError_t launch_pack_vec(const float* params, const NetLayout& L, int HT, float* vp, hipStream_t s) {
