@@ -27,9 +27,6 @@
 // workgroup.
 #pragma once
 #include "mlp_common.cuh"
-#ifndef NH_EXP_NODMA
-#define NH_EXP_NODMA 0
-#endif
 #ifndef NH_X3_PD
 #define NH_X3_PD 2
 #endif
@@ -78,7 +75,7 @@ struct Ring {
     const char* src = stream + (size_t)req_src * kBlkBytes + voff;
     char* dst = reinterpret_cast<char*>(ring) + (req & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / kWaves);
 #pragma unroll
-    for (int g = 0; g < ((NH_EXP_NODMA && req >= kRing) ? 0 : kDmaPieces / 4); ++g) {
+    for (int g = 0; g < kDmaPieces / 4; ++g) {
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 1024, 0);
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + g * 4096), NERFHIP_LPTR(dst + g * 4096), 16, 2048, 0);
@@ -92,7 +89,6 @@ struct Ring {
     blk = 0; req = 0; req_src = 0;
     asm volatile("" ::: "memory");
     request(); request(); request();
-    if (NH_EXP_NODMA) { request(); req = kRing; }
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kDmaPieces) : "memory");
     __builtin_amdgcn_s_barrier();
   }

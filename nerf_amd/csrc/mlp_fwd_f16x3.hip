@@ -8,11 +8,11 @@
 // One wave = 32 samples x all features, one wave per SIMD (512 registers), workgroup = 4 waves = 128 samples,
 // persistent (one per CU).  Stream layout = that of the bf16 kernel with every fragment replaced by its (hi, lo) pair
 // and every part padded to whole 16-pair blocks (api.hip: build_bf16_streams(pad 16) + pack.hip: pack_frags_f16x3).
-#ifndef NH_EXP_NODIR
-#define NH_EXP_NODIR 0
-#endif
-#ifndef NH_EXP_STAMP
-#define NH_EXP_STAMP 0
+// -DNERFHIP_DIAG_STAMPS=1 makes a DIAGNOSTIC library (scripts/x3_stamps.sh builds its own copy under build/, never the
+// shipped one): one wave records s_memtime at the part boundaries of its 4th tile and the workgroup overwrites the first
+// bytes of `craw` with them -- results of that build are wrong by construction.
+#ifndef NERFHIP_DIAG_STAMPS
+#define NERFHIP_DIAG_STAMPS 0
 #endif
 #include "f16x3_common.cuh"
 #include <algorithm>
@@ -77,11 +77,7 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
       // add().relu() (nerfCoreBlock.scala:67): + (Wd.enc(dir) + bd + bf) of the sample's ray, fp32; registers 2P, 2P+1
       // hold features 32 OT + 8 (P/2) + 2 (P%2) + 4h + {0, 1}
       const float* df = dirfeat + (int64_t)ray * (32 * HT) + 32 * OT_IDX + 8 * (P / 2) + 2 * (P % 2) + 4 * h;
-#if NH_EXP_NODIR
-      const f32x2 d = {0.1f, 0.2f}; (void)df;
-#else
       const f32x2 d = *reinterpret_cast<const f32x2*>(df);
-#endif
       split_into(hid.v[OT_IDX][P / 4], P % 4, fmaxf(fmaf(a[2 * P], kWInv, d[0]), 0.f), fmaxf(fmaf(a[2 * P + 1], kWInv, d[1]), 0.f));
     } else if constexpr (MODE == 2) {
       // reshape(...,9,3).mul(SH).sum(-2) (:55): c[k] = sum_j q[3j+k] * Y_j(dir); rows 0..26 of tile 0
@@ -160,7 +156,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
   __syncthreads();   // vectors visible
   rg.start();
 
-#if NH_EXP_STAMP
+#if NERFHIP_DIAG_STAMPS
   uint64_t st[16]; int it = 0;
 #define STAMP(i) do { if (it == 3) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -230,12 +226,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
       c[0] += __shfl_xor(c[0], 32); c[1] += __shfl_xor(c[1], 32); c[2] += __shfl_xor(c[2], 32);
     }
     STAMP(12);
-#if NH_EXP_STAMP
+#if NERFHIP_DIAG_STAMPS
     ++it;
 #endif
     if (valid && h == 0) { craw[(int64_t)m * 3 + 0] = c[0]; craw[(int64_t)m * 3 + 1] = c[1]; craw[(int64_t)m * 3 + 2] = c[2]; }
   }   // tile loop
-#if NH_EXP_STAMP
+#if NERFHIP_DIAG_STAMPS
   if (blockIdx.x == 5 && tid == 0) for (int i = 0; i < 13; ++i) reinterpret_cast<uint64_t*>(craw)[i] = st[i];
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup

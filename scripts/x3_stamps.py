@@ -1,4 +1,4 @@
-"""Diagnostic (library built with -DNH_EXP_STAMP=1): cycle stamps of one wave's 4th tile of the split-f16 forward."""
+"""Diagnostic (library built by scripts/x3_stamps.sh with -DNERFHIP_DIAG_STAMPS=1): cycle stamps of one wave's 4th tile of the split-f16 forward."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -253,6 +253,32 @@ def test_mlp_forward_ragged_tile(G, dtype):
     blk.close()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mlp_forward_far_positions(G, dtype):
+    """Encoding arguments beyond the short sin/cos routine's range (|p| * 2^(posL-1) > 8192, mlp_common.cuh: kTrigMax):
+    waves whose samples are all far, and waves that mix far and near samples, take libm's functions; same bar."""
+    c = H.CONFIGS["small_dir"]
+    o = Oracle(c)
+    n, S = 96, 16
+    ro, rd, b, _ = H.make_rays(n, 11)
+    ro = ro.copy()
+    ro[:40] *= 2000.0          # |p| ~ 8000: arguments up to 6.4e4
+    ro[40:64:2] *= 2000.0      # every other ray: far and near samples inside one wave
+    z = np.sort(H.det_uniform(n * S, 6, 2.0, 6.0).reshape(n, S), axis=1)
+    params = H.make_params(c, 4)
+    blk = G.make_block(c, dtype=dtype)
+    blk.set_params(params)
+    sig, craw = G.empty(n, S), G.empty(n, S, 3)
+    blk.k_mlp_forward(1, G.dev(ro), G.dev(rd), G.dev(rd), G.dev(z), n, S, sig, craw)
+    blk.synchronize()
+    npc = o.net_param_count()
+    rs, rc = o.mlp_forward(params[npc:2 * npc], False, True, ro, rd, rd, z)
+    # raw positions of 8000 enter layer 0 as they are: outputs scale with them, so the bar is relative to the output scale
+    np.testing.assert_allclose(sig.cpu().numpy()[:, :S - 1], rs[:, :S - 1], rtol=2e-4, atol=2e-5 * max(1.0, np.abs(rs).max()))
+    np.testing.assert_allclose(craw.cpu().numpy(), rc, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(rc).max()))
+    blk.close()
+
+
 E2E = ["small_dir_eval", "small_sh_eval", "small_flat_eval", "small_opts_eval", "full_eval"]
 
 
