@@ -403,7 +403,7 @@ def main():
             return r
         hbm_kernels = {"workload": f"{n_frame} rays x {S} samples (resampling: 64 coarse -> 192 fine)",
                        "timing": "HIP events on the launch stream, 10 launches back to back; rocprofv3 --kernel-trace of "
-                                 "the same shape: profiles/r2_hbm_after_kernel_stats.csv (scripts/hbm_prof.sh)",
+                                 "the same shape: profiles/r2_final_hbm_kernel_stats.csv (scripts/hbm_prof.sh)",
                        "composite_fwd": hbm(ms_cf, 24.0 * nsamp + 20.0 * n_frame, "composite_fwd_k<3>"),
                        "composite_bwd": hbm(ms_cb, 40.0 * nsamp + 12.0 * n_frame, "composite_bwd_k<3>"),
                        "sample_pdf": hbm(ms_sp, n_frame * (8.0 * 64 + 4.0 * 192), "sample_pdf_kernel")}
@@ -451,14 +451,14 @@ def pmc_traffic(dom, dtype):
     tot = 0.0
     try:
         for kind, col, mul in (("fetchsize", "FETCH_SIZE", 2.0), ("writesize", "WRITE_SIZE", 1.0)):
-            path = os.path.join(ROOT, "profiles", f"r1_final_{dtype}_pmc_{kind}.csv")
+            path = os.path.join(ROOT, "profiles", f"r2_final_{dtype}_pmc_{kind}.csv")
             for r in csv.DictReader(open(path)):
                 if sub in r["kernel"]:
                     tot += mul * float(r[col]) * 1024.0 / 3.0     # 3 profiled steps
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
     return {"traffic": round(tot), "traffic_unit": "bytes per train step (all launches of the kernel)",
-            "traffic_source": f"profiles/r1_final_{dtype}_pmc_fetchsize.csv, _writesize.csv"}
+            "traffic_source": f"profiles/r2_final_{dtype}_pmc_fetchsize.csv, _writesize.csv"}
 
 
 def hbm_traffic(kname):
@@ -470,12 +470,12 @@ def hbm_traffic(kname):
     tot = 0.0
     try:
         for kind, col, mul in (("fetchsize", "FETCH_SIZE", 2.0), ("writesize", "WRITE_SIZE", 1.0)):
-            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r2_hbm_after_pmc_{kind}.csv"))):
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r2_final_hbm_pmc_{kind}.csv"))):
                 if kname in r["kernel"]:
                     tot += mul * float(r[col]) * 1024.0 / float(r["dispatches"])
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return {"traffic": None}
-    return {"traffic": round(tot), "traffic_source": "profiles/r2_hbm_after_pmc_fetchsize.csv, _writesize.csv"} if tot else {"traffic": None}
+    return {"traffic": round(tot), "traffic_source": "profiles/r2_final_hbm_pmc_fetchsize.csv, _writesize.csv"} if tot else {"traffic": None}
 
 
 def cpu_baseline(base, t_o, t_d, t_b, t_l, seconds):
