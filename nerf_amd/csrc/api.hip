@@ -390,10 +390,12 @@ int dir_features(nerfhip* h, Net& n, const float* viewdir, int64_t nr, bool trai
 int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const float* d, const float* z, int64_t nr, int S,
                 float* sigma, float* craw, bool want_rgb) {
   Scope sc(h, P_MLP_FWD);
-  if (h->cfg.dtype == NERFHIP_F16X3 && !train_store) {
+  if (h->cfg.dtype == NERFHIP_F16X3) {   // training forward: the same kernels, filling the fp32 path's activation store
+    ActStore st = n.st;
+    st.Mpad = (nr * S + kTile - 1) / kTile * kTile;
     HIPCHK(h, launch_mlp_fwd_f16x3(net_args(h, n), want_rgb ? n.d_x3_full : n.d_x3_sigma, n.d_bvec, o, d, z, n.d_dirfeat, nr * S, S,
                                    sigma, craw, want_rgb ? 1 : 0, (int)((want_rgb ? n.x3_full.size() : n.x3_sigma.size()) / 16),
-                                   h->n_cu, h->stream));
+                                   h->n_cu, train_store ? &st : nullptr, h->stream));
   } else if (h->cfg.dtype == NERFHIP_BF16) {
     BfStore bst = n.bst;
     bst.Mpad = (nr * S + 255) / 256 * 256;

@@ -67,6 +67,11 @@ struct Ring {
   float* ring;
   uint32_t ring_addr;   // LDS byte address of slot 0 + lane*16
   int nblk, blk, req, req_src, wave, lane;
+  // training kernel: VMEM operations of this wave behind the pieces of block blk+1 (young_a: up to the request of
+  // block blk+2, young_b: since) -- activation / mask stores, counted by note(); vmcnt retires in order, so counting
+  // them lets the stores stay in flight across sync points (as bf16_common.cuh: BfRing)
+  int young_a, young_b;
+  __device__ __forceinline__ void note(int n) { young_b += n; }
   uint32_t voff;        // this lane's byte offset inside a block: wave quarter + lane * 16
   __device__ __forceinline__ void request() {
     // one wave moves its quarter of the block with 8 LDS-DMA instructions of 1 KiB; the piece offset rides in the
@@ -91,13 +96,17 @@ struct Ring {
     request(); request(); request();
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kDmaPieces) : "memory");
     __builtin_amdgcn_s_barrier();
+    young_a = young_b = 0;
   }
   // sync point P_blk: block blk+1 visible to every wave, slot of block blk-1 handed to block blk+3.  vmcnt retires in
   // order: at most the pieces of block blk+2 may still be outstanding (the kernel's own stores only make it stricter)
+  template <bool COUNT>
   __device__ __forceinline__ void sync_point() {
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kDmaPieces) : "memory");
+    if constexpr (COUNT) wait_vm_at_most(young_a + kDmaPieces + young_b);
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kDmaPieces) : "memory");
     __builtin_amdgcn_s_barrier();
     request();
+    if constexpr (COUNT) { young_a = young_b; young_b = 0; }
   }
   __device__ __forceinline__ uint32_t slot_addr(int b) const { return ring_addr + (uint32_t)(b & (kRing - 1)) * kBlkBytes; }
 };
@@ -190,7 +199,8 @@ struct EpiPieces {   // runs the pieces of tile OT_IDX scheduled at k-step offse
   }
 };
 
-template <int KS, int OT, class BSel, class Epi, bool BIAS, int J>
+// COUNT: the kernel issues VMEM operations of its own between the sync points (Ring::note)
+template <int KS, int OT, class BSel, class Epi, bool BIAS, bool COUNT, int J>
 struct PartStep {
   using S = PartSched<KS, OT, BIAS>;
   static __device__ __forceinline__ void run(Ring& rg, int blk0, uint32_t bias_addr, f16x8 (&fr)[kPD + 1][2], BiasBuf& bias,
@@ -222,8 +232,8 @@ struct PartStep {
     acc[ot & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, as_f16x8(b.hi), acc[ot & 1], 0, 0, 0);
     if constexpr (ot >= 1) EpiPieces<KS, Epi, ot - 1, ks>::run(epi, acc[(ot - 1) & 1]);
     if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<KS, Epi, ot, -1>::run(epi, acc[ot & 1]);
-    if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkPairs; rg.sync_point(); }
-    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, BIAS, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
+    if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkPairs; rg.template sync_point<COUNT>(); }
+    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, BIAS, COUNT, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   }
 };
 
@@ -236,7 +246,7 @@ __device__ __forceinline__ void prime_pairs(f16x8 (&fr)[kPD + 1][2], uint32_t ad
   }
 }
 // Runs one part that starts at block rg.blk (block-aligned) and leaves rg.blk at the next part's first block.
-template <int KS, int OT, bool BIAS = true, class BSel, class Epi>
+template <int KS, int OT, bool BIAS = true, bool COUNT = false, class BSel, class Epi>
 __device__ __forceinline__ void run_part(Ring& rg, uint32_t bias_addr, const BSel& bsel, Epi& epi) {
   static_assert(!BIAS || KS >= 2 || OT == 1, "the init rows of the next tile are requested at k-step 1");
   static_assert(kPD < kBlkPairs, "the prefetch must stay inside the block after the current one");
@@ -248,7 +258,7 @@ __device__ __forceinline__ void run_part(Ring& rg, uint32_t bias_addr, const BSe
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (BIAS) bias_read<0>(bias, bias_addr);
   prime_pairs<S::NF, 0>(fr, rg.slot_addr(blk0));
-  PartStep<KS, OT, BSel, Epi, BIAS, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
+  PartStep<KS, OT, BSel, Epi, BIAS, COUNT, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   wait_lgkm_n<0>();
   __builtin_amdgcn_sched_barrier(0);
   rg.blk = blk0 + (S::NF + kBlkPairs - 1) / kBlkPairs;

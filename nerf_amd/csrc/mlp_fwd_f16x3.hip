@@ -5,6 +5,10 @@
 // Held to the SAME parity bars as the fp32 kernels (tests: every fp32 render test also runs with dtype f16x3).
 // Positions, the encoding's sin/cos (accurate ones, mlp_common.cuh, not the hardware approximations of the bf16 path), biases,
 // the per-ray view-direction branch and all accumulators are fp32.
+// TRAIN variant (forward of a training step with dtype f16x3; backward and weight gradient stay on the fp32 kernels):
+// the same arithmetic, and every post-ReLU activation, the encoding, the colour hidden layer and the ReLU sign bits are
+// written in fp32 into the fp32 path's activation store (common.h: ActStore, tile-major -- the accumulator layout of
+// the 32x32 f16 MFMA is that of the 32x32 fp32 one, so a register goes out exactly as mlp_fwd.hip writes it).
 // One wave = 32 samples x all features, one wave per SIMD (512 registers), workgroup = 4 waves = 128 samples,
 // persistent (one per CU).  Stream layout = that of the bf16 kernel with every fragment replaced by its (hi, lo) pair
 // and every part padded to whole 16-pair blocks (api.hip: build_bf16_streams(pad 16) + pack.hip: pack_frags_f16x3).
@@ -49,12 +53,46 @@ struct SelHid {
 // comes out of an asm-free register costs a canonicalising v_max_f32 as well
 __device__ __forceinline__ float relu_bits(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
 
-template <int WT>
+// what the TRAIN epilogues need to write a tile into the activation store
+struct StoreCtx {
+  float* dst;          // wave-uniform: this wave's 32-sample tile block of the layer's buffer (mlp_common.cuh: tile_block)
+  uint32_t voff;       // tile_voff(lane)
+  uint32_t* mask;      // this lane's word 0 of the layer's sign-bit slot (mask_ptr(.., w = 0, ..)); word w at + w * Mpad
+  int64_t Mpad;
+};
+// a pointer that IS wave-uniform, made so for the compiler (the asm stores take their base in SGPRs)
+__device__ __forceinline__ float* uniform_ptr(float* p) {
+  const uint64_t u = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return (float*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+// sign bit of a post-ReLU value, at bit position POS of a mask word ("> 0" on the integer bits, mlp_common.cuh)
+template <int POS>
+__device__ __forceinline__ uint32_t sign_bit_at(float v) { return (uint32_t)min(__builtin_bit_cast(int, v), 1) << POS; }
+
+template <int WT, bool TRAIN>
 struct EpiTrunk {   // relu + split -> B operand pairs of the next layer; piece P = registers 2P, 2P+1 of the tile
   ActRegs<WT>& out;
+  Ring& rg;
+  StoreCtx sc;
+  uint32_t mw;
   static constexpr int kPieces = 8;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
-    split_scaled_into(out.v[OT_IDX][P / 4], P % 4, relu_bits(a[2 * P]), relu_bits(a[2 * P + 1]));
+    if constexpr (!TRAIN) {
+      split_scaled_into(out.v[OT_IDX][P / 4], P % 4, relu_bits(a[2 * P]), relu_bits(a[2 * P + 1]));
+    } else {
+      const float v0 = relu_bits(a[2 * P]) * kWInv, v1 = relu_bits(a[2 * P + 1]) * kWInv;   // exact: a power of two
+      store_reg<OT_IDX, 2 * P>(sc.dst, sc.voff, v0);
+      store_reg<OT_IDX, 2 * P + 1>(sc.dst, sc.voff, v1);
+      rg.note(2);
+      if constexpr (P == 0 && (OT_IDX & 1) == 0) mw = 0u;
+      mw |= sign_bit_at<16 * (OT_IDX & 1) + 2 * P>(v0) | sign_bit_at<16 * (OT_IDX & 1) + 2 * P + 1>(v1);
+      if constexpr (P == kPieces - 1 && ((OT_IDX & 1) == 1 || OT_IDX == WT - 1)) {
+        sc.mask[(int64_t)(OT_IDX / 2) * sc.Mpad] = mw;
+        rg.note(1);
+      }
+      split_into(out.v[OT_IDX][P / 4], P % 4, v0, v1);
+    }
   }
 };
 struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
@@ -64,10 +102,13 @@ struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.sc
     if (valid && h == 0) sigma[m] = a[0] * kWInv;
   }
 };
-template <int HT, int MODE>
+template <int HT, int MODE, bool TRAIN>
 struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
   ActRegs<HT>& hid; float (&c)[3];
   const float* dirfeat; int ray; int m; bool valid; float* sigma; int h;
+  Ring& rg;
+  StoreCtx sc;      // TRAIN, mode 1: the colour hidden layer (ActStore::hc) and its sign bits (slot D)
+  uint32_t mw;
   static constexpr int kPieces = 8;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
     if constexpr (OT_IDX == HT) {
@@ -78,7 +119,19 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
       // hold features 32 OT + 8 (P/2) + 2 (P%2) + 4h + {0, 1}
       const float* df = dirfeat + (int64_t)ray * (32 * HT) + 32 * OT_IDX + 8 * (P / 2) + 2 * (P % 2) + 4 * h;
       const f32x2 d = *reinterpret_cast<const f32x2*>(df);
-      split_into(hid.v[OT_IDX][P / 4], P % 4, fmaxf(fmaf(a[2 * P], kWInv, d[0]), 0.f), fmaxf(fmaf(a[2 * P + 1], kWInv, d[1]), 0.f));
+      const float v0 = fmaxf(fmaf(a[2 * P], kWInv, d[0]), 0.f), v1 = fmaxf(fmaf(a[2 * P + 1], kWInv, d[1]), 0.f);
+      if constexpr (TRAIN) {
+        store_reg<OT_IDX, 2 * P>(sc.dst, sc.voff, v0);
+        store_reg<OT_IDX, 2 * P + 1>(sc.dst, sc.voff, v1);
+        rg.note(2);
+        if constexpr (P == 0 && (OT_IDX & 1) == 0) mw = 0u;
+        mw |= sign_bit_at<16 * (OT_IDX & 1) + 2 * P>(v0) | sign_bit_at<16 * (OT_IDX & 1) + 2 * P + 1>(v1);
+        if constexpr (P == kPieces - 1 && ((OT_IDX & 1) == 1 || OT_IDX == HT - 1)) {
+          sc.mask[(int64_t)(OT_IDX / 2) * sc.Mpad] = mw;
+          rg.note(1);
+        }
+      }
+      split_into(hid.v[OT_IDX][P / 4], P % 4, v0, v1);
     } else if constexpr (MODE == 2) {
       // reshape(...,9,3).mul(SH).sum(-2) (:55): c[k] = sum_j q[3j+k] * Y_j(dir); rows 0..26 of tile 0
       const float* Y = dirfeat + (int64_t)ray * 12;
@@ -111,19 +164,23 @@ struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
 };
 
 // positionCode (nerfCoreBlock.scala:127-136) of this lane's 32 of the 64 (padded) features, split into operand pairs
-template <bool RED>
-__device__ __forceinline__ void encode(ActRegs<2>& enc, float px, float py, float pz, int E, int h) {
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        split_into(enc.v[kt][s], i, code_value_h<RED>(px, py, pz, 32 * kt + feature(s, 0, 2 * i), h, E),
-                   code_value_h<RED>(px, py, pz, 32 * kt + feature(s, 0, 2 * i + 1), h, E));
+// (element 2i, 2i+1 of k-step s of k-tile kt = accumulator-layout register 8s + 2i, 8s + 2i + 1 of tile kt)
+template <bool RED, bool TRAIN, int KT = 0, int S_ = 0, int I = 0>
+__device__ __forceinline__ void encode(ActRegs<2>& enc, float px, float py, float pz, int E, int h, const StoreCtx& sc) {
+  if constexpr (KT < 2) {
+    const float v0 = code_value_h<RED>(px, py, pz, 32 * KT + feature(S_, 0, 2 * I), h, E);
+    const float v1 = code_value_h<RED>(px, py, pz, 32 * KT + feature(S_, 0, 2 * I + 1), h, E);
+    if constexpr (TRAIN) {
+      store_reg<KT, 8 * S_ + 2 * I>(sc.dst, sc.voff, v0);
+      store_reg<KT, 8 * S_ + 2 * I + 1>(sc.dst, sc.voff, v1);
+    }
+    split_into(enc.v[KT][S_], I, v0, v1);
+    constexpr int nxt = (KT * 2 + S_) * 4 + I + 1;
+    encode<RED, TRAIN, nxt / 8, (nxt / 4) % 2, nxt % 4>(enc, px, py, pz, E, h, sc);
+  }
 }
 
-template <int WT, int MODE>
+template <int WT, int MODE, bool TRAIN>
 __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs net, const char* __restrict__ stream,
                                                                        const float* __restrict__ bvec,
                                                                        const float* __restrict__ rays_o,
@@ -131,7 +188,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
                                                                        const float* __restrict__ z,
                                                                        const float* __restrict__ dirfeat, int64_t M, int S,
                                                                        float* __restrict__ sigma, float* __restrict__ craw,
-                                                                       int want_rgb, int nblk, int ntiles) {
+                                                                       int want_rgb, int nblk, int ntiles, ActStore st) {
   constexpr int R = 32 * WT;
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring (kRing x 32 KiB) | vectors
@@ -175,22 +232,33 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     const float pz = __fadd_rn(rays_o[(int64_t)ray * 3 + 2], __fmul_rn(rays_d[(int64_t)ray * 3 + 2], zz));
     // the encoding is computed once per sample and kept (32 registers) for the skip layers: its sin/cos are the
     // accurate ones, far too expensive to recompute
+    // TRAIN: this wave's 32-sample tile of the activation store (tile index as in mlp_fwd.hip: 4 per workgroup tile)
+    const int tix = tile * kWaves + wave;
+    const uint32_t svoff = tile_voff(lane);
+    auto store_ctx = [&](float* buf, int rows, int slot) __attribute__((always_inline)) {
+      return StoreCtx{TRAIN ? uniform_ptr(tile_block(buf, tix, rows)) : nullptr, svoff, TRAIN ? mask_ptr(st.mask, slot, h, 0, st.Mpad, m) : nullptr,
+                      st.Mpad};
+    };
     ActRegs<2> enc;
-    if (trig_reduced(px, py, pz, net.E)) encode<true>(enc, px, py, pz, net.E, h);   // wave-uniform: the usual case
-    else encode<false>(enc, px, py, pz, net.E, h);
+    {
+      const StoreCtx sce = store_ctx(st.enc, 64, 0);
+      if (trig_reduced(px, py, pz, net.E)) encode<true, TRAIN>(enc, px, py, pz, net.E, h, sce);   // wave-uniform: the usual case
+      else encode<false, TRAIN>(enc, px, py, pz, net.E, h, sce);
+      if constexpr (TRAIN) rg.note(32);
+    }
 
     STAMP(1);
     ActRegs<WT> act, nxt;
     {
-      EpiTrunk<WT> epi{act};
-      run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
+      EpiTrunk<WT, TRAIN> epi{act, rg, store_ctx(st.act, R, 0), 0u};
+      run_part<4, WT, true, TRAIN>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
     }
     STAMP(2);
-    auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) {
-      EpiTrunk<WT> epi{out};
+    auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) __attribute__((always_inline)) {
+      EpiTrunk<WT, TRAIN> epi{out, rg, store_ctx(st.act + (int64_t)l * R * st.Mpad, R, l), 0u};
       const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
-      if ((net.skip_mask >> (l - 1)) & 1u) run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{in, &enc}, epi);
-      else run_part<2 * WT, WT>(rg, baddr, SelAct<WT>{in, nullptr}, epi);
+      if ((net.skip_mask >> (l - 1)) & 1u) run_part<2 * WT + 4, WT, true, TRAIN>(rg, baddr, SelAct<WT>{in, &enc}, epi);
+      else run_part<2 * WT, WT, true, TRAIN>(rg, baddr, SelAct<WT>{in, nullptr}, epi);
     };
     int l = 1;
     for (; l + 1 < D; l += 2) {
@@ -208,20 +276,20 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     if (!want_rgb) {
       // sigma-only stream: one tile, row 0 = density row (nerfCoreBlock.scala:39-40)
       EpiSigma epi{sigma, m, valid, h};
-      run_part<2 * WT, 1>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, nullptr}, epi);
+      run_part<2 * WT, 1, true, TRAIN>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, nullptr}, epi);
       continue;
     }
     // head: HT colour tiles, then the density tile
     ActRegs<HT> hid;
     float c[3] = {0.f, 0.f, 0.f};
-    EpiHead<HT, MODE> epih{hid, c, dirfeat, ray, m, valid, sigma, h};
+    EpiHead<HT, MODE, TRAIN> epih{hid, c, dirfeat, ray, m, valid, sigma, h, rg, store_ctx(st.hc, 32 * HT, D), 0u};
     STAMP(10);
-    run_part<2 * WT, HT + 1>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
+    run_part<2 * WT, HT + 1, true, TRAIN>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
     STAMP(11);
     if constexpr (MODE == 1) {
       // colour output layer: Linear(3) over the H2 hidden features, as one MFMA tile (rows 0..2)
       EpiColour epic{c, h};
-      run_part<2 * HT, 1>(rg, haddr + (uint32_t)((HT + 1) * 32) * 4u, SelHid<HT>{hid}, epic);
+      run_part<2 * HT, 1, true, TRAIN>(rg, haddr + (uint32_t)((HT + 1) * 32) * 4u, SelHid<HT>{hid}, epic);
     } else if constexpr (MODE == 2) {
       c[0] += __shfl_xor(c[0], 32); c[1] += __shfl_xor(c[1], 32); c[2] += __shfl_xor(c[2], 32);
     }
@@ -240,14 +308,18 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
 template <int WT, int MODE>
 static hipError_t launch_one(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o, const float* rays_d,
                              const float* z, const float* dirfeat, int64_t M, int S, float* sigma, float* craw, int want_rgb,
-                             int nblk, int n_cu, hipStream_t stream) {
+                             int nblk, int n_cu, const ActStore* st, hipStream_t stream) {
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   const size_t lds = (size_t)kRing * kBlkBytes + ((size_t)net.D * 32 * WT + (HT + 1) * 32 + 32) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);
   const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kWaves);   // one persistent workgroup per CU
-  hipLaunchKernelGGL((mlp_fwd_f16x3_kernel<WT, MODE>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o, rays_d,
-                     z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles);
+  if (st)
+    hipLaunchKernelGGL((mlp_fwd_f16x3_kernel<WT, MODE, true>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
+                       rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles, *st);
+  else
+    hipLaunchKernelGGL((mlp_fwd_f16x3_kernel<WT, MODE, false>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
+                       rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles, ActStore{});
   return hipGetLastError();
 }
 
@@ -263,19 +335,26 @@ static hipError_t launch_one(const NetArgs& net, const void* stream_w, const flo
 
 // once per device, with that device current (nerfhip_create)
 hipError_t prepare_mlp_fwd_f16x3(int W, int mode) {
-#define NH_X3_PREP(WT_, MODE_) \
-  return hipFuncSetAttribute((const void*)x3::mlp_fwd_f16x3_kernel<WT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define NH_X3_PREP(WT_, MODE_)                                                                                                     \
+  {                                                                                                                                \
+    hipError_t e_ = hipFuncSetAttribute((const void*)x3::mlp_fwd_f16x3_kernel<WT_, MODE_, false>,                                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+    if (e_ != hipSuccess) return e_;                                                                                               \
+    return hipFuncSetAttribute((const void*)x3::mlp_fwd_f16x3_kernel<WT_, MODE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               160 * 1024);                                                                                        \
+  }
   NH_X3_CASES(NH_X3_PREP)
 #undef NH_X3_PREP
 }
 
 // stream_w: the full pair stream when want_rgb, else the sigma-only one (api.hip)
+// st: the fp32 activation store to fill (training forward), or null
 hipError_t launch_mlp_fwd_f16x3(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                 const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                                float* craw, int want_rgb, int nblk, int n_cu, hipStream_t stream) {
+                                float* craw, int want_rgb, int nblk, int n_cu, const ActStore* st, hipStream_t stream) {
   const int W = net.W, mode = net.mode;
 #define NH_X3_LAUNCH(WT_, MODE_) \
-  return x3::launch_one<WT_, MODE_>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, stream)
+  return x3::launch_one<WT_, MODE_>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, st, stream)
   NH_X3_CASES(NH_X3_LAUNCH)
 #undef NH_X3_LAUNCH
 }
