@@ -53,11 +53,13 @@ struct Net {
   FragDesc* d_bf_bwd_desc = nullptr;
   void* d_bf_bwd = nullptr;
   // split-f16 path (cfg.dtype == NERFHIP_F16X3): forward streams of (hi, lo) fragment pairs (f16x3_common.cuh)
-  std::vector<FragDesc> x3_full, x3_sigma;
+  std::vector<FragDesc> x3_full, x3_sigma, x3_bwd;   // x3_bwd: transposed matrices, for the backward kernel
   FragDesc* d_x3_full_desc = nullptr;
   FragDesc* d_x3_sigma_desc = nullptr;
+  FragDesc* d_x3_bwd_desc = nullptr;
   void* d_x3_full = nullptr;
   void* d_x3_sigma = nullptr;
+  void* d_x3_bwd = nullptr;
   BfStore bst{};                                // bf16 training store (allocated on first training call)
   float* d_dirfeat = nullptr;  // [max_rays][max(32*HT, 12)]
   float* d_encdirT = nullptr;  // training, mode 1: [32][Bpad]
@@ -251,35 +253,40 @@ void build_fwd_streams(const Net& n, int pad_to, std::vector<FragDesc>& out_full
 
 }
 
-void build_bf16_streams(Net& n) {
+// backward stream (mlp_bwd_bf16.hip, mlp_bwd_f16x3.hip): element (row = input feature i, k = output feature) = M[k][i];
+// every part padded to pad_to descriptors (one ring block: 32 fragments, or 16 (hi, lo) pairs)
+void build_bwd_stream(const Net& n, int pad_to, std::vector<FragDesc>& out) {
   const NetLayout& L = n.L;
   const int W = L.W, WT = n.WT;
   const int HT = L.mode == 1 ? std::max(1, WT / 2) : 1;
-  auto pad = [](std::vector<FragDesc>& v) {
-    while (v.size() % 32) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 0});
+  auto pad = [pad_to](std::vector<FragDesc>& v) {
+    while (v.size() % pad_to) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 0});
   };
-  build_fwd_streams(n, 32, n.bf_full, n.bf_sigma);
-  // backward stream (mlp_bwd_bf16.hip): element (row = input feature i, k = output feature) = M[k][i]
   auto tfrag = [&](int64_t off, int ld, int row0, int nrows, int col0, int kvalid, int sidx) {
-    n.bf_bwd.push_back(FragDesc{off, ld, row0, nrows, col0, std::max(0, std::min(32, kvalid)), sidx, 1});
+    out.push_back(FragDesc{off, ld, row0, nrows, col0, std::max(0, std::min(32, kvalid)), sidx, 1});
   };
-  n.bf_bwd.clear();
+  out.clear();
   if (L.mode == 1) {   // Wc^T: rows = hidden features, k = colour channel (3)
     for (int ot = 0; ot < HT; ++ot) tfrag(L.wc_off, L.H2, 32 * ot, L.H2, 0, 3, 0);
-    pad(n.bf_bwd);
+    pad(out);
   }
   for (int ot = 0; ot < WT; ++ot) {   // head: Wf^T (k = head row) then the density k-step (k = 0: w_sigma)
     for (int kt = 0; kt < HT; ++kt)
       for (int sidx = 0; sidx < 2; ++sidx) tfrag(L.wf_off, W, 32 * ot, W, 32 * kt, L.head_rows - 32 * kt, sidx);
     tfrag(L.ws_off, W, 32 * ot, W, 0, 1, 0);
   }
-  pad(n.bf_bwd);
+  pad(out);
   for (int l = L.D - 1; l >= 1; --l) {   // W_l^T restricted to the W activation inputs (the encoding has no gradient)
     for (int ot = 0; ot < WT; ++ot)
       for (int kt = 0; kt < WT; ++kt)
         for (int sidx = 0; sidx < 2; ++sidx) tfrag(L.w_off[l], L.fan_in[l], 32 * ot, W, 32 * kt, 32, sidx);
-    pad(n.bf_bwd);
+    pad(out);
   }
+}
+
+void build_bf16_streams(Net& n) {
+  build_fwd_streams(n, 32, n.bf_full, n.bf_sigma);
+  build_bwd_stream(n, 32, n.bf_bwd);
 }
 
 NetArgs net_args(const nerfhip* h, const Net& n) {
@@ -369,6 +376,7 @@ int repack(nerfhip* h) {
     if (h->cfg.dtype == NERFHIP_F16X3) {   // + the render kernel's pair streams (training stays on the fp32 kernels)
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->stream));
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, h->stream));
+      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_bwd_desc, (int)n.x3_bwd.size(), n.d_x3_bwd, h->stream));
       HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, 64.0f, h->stream));
     }
   }
@@ -592,7 +600,7 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
     CCHK(prepare_mlp_fwd_bf16(c.W, L.mode));
     CCHK(prepare_mlp_bwd_bf16(c.W, L.mode));
   }
-  if (c.dtype == NERFHIP_F16X3) CCHK(prepare_mlp_fwd_f16x3(c.W, L.mode));
+  if (c.dtype == NERFHIP_F16X3) { CCHK(prepare_mlp_fwd_f16x3(c.W, L.mode)); CCHK(prepare_mlp_bwd_f16x3(c.W, L.mode)); }
   CCHK(hipGetSymbolAddress((void**)&h->static_scratch, HIP_SYMBOL(scratch)));   // this device's copy of the array
   CCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
@@ -647,7 +655,12 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
     }
     if (c.dtype == NERFHIP_F16X3) {
       build_fwd_streams(n, 16, n.x3_full, n.x3_sigma);
+      build_bwd_stream(n, 16, n.x3_bwd);
       const size_t padf = 4 * 32;   // the LDS ring requests up to 3 blocks (of 32 fragments) past the end
+      CCHK(dalloc(&n.d_x3_bwd_desc, n.x3_bwd.size()));
+      CCHK(hipMemcpy(n.d_x3_bwd_desc, n.x3_bwd.data(), n.x3_bwd.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMalloc(&n.d_x3_bwd, (2 * n.x3_bwd.size() + padf) * 1024));
+      CCHK(hipMemsetAsync(n.d_x3_bwd, 0, (2 * n.x3_bwd.size() + padf) * 1024, h->stream));
       CCHK(dalloc(&n.d_x3_full_desc, n.x3_full.size()));
       CCHK(dalloc(&n.d_x3_sigma_desc, n.x3_sigma.size()));
       CCHK(hipMemcpy(n.d_x3_full_desc, n.x3_full.data(), n.x3_full.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
@@ -686,7 +699,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
-    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
+    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_bwd_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.d_x3_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
     fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
     fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.st.mask); fr(n.d_dsigma); fr(n.d_dcraw);
   }

@@ -78,6 +78,11 @@ hipError_t prepare_mlp_fwd_f16x3(int W, int mode);
 hipError_t launch_mlp_fwd_f16x3(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                 const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
                                 float* craw, int want_rgb, int nblk, int n_cu, const ActStore* st, hipStream_t stream);
+// mlp_bwd_f16x3.hip: backward-data pass of a training step with dtype f16x3 (reads/writes the fp32 activation store)
+hipError_t prepare_mlp_bwd_f16x3(int W, int mode);
+hipError_t launch_mlp_bwd_f16x3(const ActStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
+                                const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu,
+                                hipStream_t stream);
 // wgrad_bf16.hip: one slice of the sample axis of one product, operands in the bf16 store's operand layout
 struct WgradBfItem {
   const uint16_t* A;   // fragment (tile 0, first k-tile of the A rows, s = 0)
