@@ -212,7 +212,7 @@ def main():
 
     # ---- everything below is extra reporting next to the headline numbers above; with one rank a failure in it is
     # recorded in the line instead of losing the line (with several ranks it must propagate: the others would hang)
-    render_bf16 = render_f16x3 = train_bf16 = config5 = render_pose = hbm_kernels = cpu = None
+    render_bf16 = render_f16x3 = train_f16x3 = train_bf16 = config5 = render_pose = hbm_kernels = cpu = None
     extras_error = None
     try:
         # ---- render legs on the other MFMA paths, same frames: bf16 (BASELINE configs[4] arithmetic; parity bar 1e-2 abs,
@@ -254,7 +254,7 @@ def main():
 
         # ---- bf16-MFMA training legs: the same batch (configs[3] arithmetic in bf16), and BASELINE configs[4]:
         # 1024x1024 forward-facing scene, NDC rays (llff.scala:96-132), 64 + 256 samples per ray
-        def timed_train(blk, o_, d_, b_, l_, nsteps):
+        def timed_train(blk, o_, d_, b_, l_, nsteps, dt="bf16"):
             g = grad_tensor(blk) if dp else None
             if native:
                 native_init(blk)
@@ -285,10 +285,22 @@ def main():
                 d_t = float(t_.item())
             ks = {"mlp_fwd": (pr["mlp_fwd_ms"], pr["mlp_fwd_flop"]), "mlp_bwd": (pr["mlp_bwd_ms"], pr["mlp_bwd_flop"]),
                   "mlp_wgrad": (pr["mlp_wgrad_ms"], pr["mlp_wgrad_flop"])}
-            return {"value": round(world * B * nsteps / d_t, 1), "unit": "rays/s", "dtype": "bf16", "steps": nsteps,
+            return {"value": round(world * B * nsteps / d_t, 1), "unit": "rays/s", "dtype": dt, "steps": nsteps,
                     "ms_per_step": round(1e3 * d_t / nsteps, 3),
                     "kernel_ms_per_step": {k: round(v[0] / nsteps, 4) for k, v in ks.items()},
                     "kernel_tflops": {k: round(v[1] / max(v[0], 1e-9) / 1e9, 1) for k, v in ks.items()}}
+
+        # ---- dtype f16x3 training: split-f16 forward and backward-data kernels (fp32-grade: held to the fp32 gradient
+        # tests at the fp32 tolerances, tests/test_gpu_train.py), fp32 weight gradient; own dtype label
+        train_f16x3 = None
+        if args.dtype == "f32" and not args.no_bf16_train:
+            tx = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=B, dtype="f16x3")))
+            tx.set_stream(stream)
+            tx.init_params(7)
+            train_f16x3 = timed_train(tx, t_o, t_d, t_b, t_l, args.steps, "f16x3")
+            train_f16x3["metric"] = "rays/sec (train step, split-f16 MFMA forward/backward, fp32-grade)"
+            tx.close()
+            note("f16x3 train leg done")
 
         train_bf16 = config5 = None
         if args.dtype == "f32" and not args.no_bf16_train:
@@ -432,7 +444,7 @@ def main():
                 # compositing samples of the fine pass)
                 "samples_per_s": round(train_rays_s * 256, 1),
                 "roofline": roofline, "render": render, "render_bf16": render_bf16, "render_f16x3": render_f16x3,
-                "train_bf16": train_bf16,
+                "train_f16x3": train_f16x3, "train_bf16": train_bf16,
                 "config5_bf16": config5, "render_pose_800": render_pose, "hbm_kernels": hbm_kernels,
                 "cpu_baseline": cpu, "extras_error": extras_error}
         print(json.dumps(line))
