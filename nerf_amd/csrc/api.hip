@@ -103,6 +103,7 @@ struct nerfhip {
   nh::WgradItem* d_items = nullptr;
   nh::WgradBfItem* d_bitems = nullptr;   // bf16 path
   std::vector<nh::WgradBfItem> bitems;
+  float* d_amax = nullptr;            // dtype f16x3: [2][kMaxD + 2] largest gradient elements of the step (mlp_bwd_f16x3.hip)
   int32_t* d_items_first = nullptr;   // [n workgroups + 1] first work entry of every persistent workgroup
   std::vector<int32_t> items_first;
   std::vector<nh::WgradItem> items;
@@ -595,6 +596,7 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
                           std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
   // kernels with > 64 KiB of dynamic LDS: raise the limit on THIS device (per handle, not per process)
   CCHK(prepare_wgrad_f32());
+  CCHK(prepare_wgrad_f16x3());
   if (c.dtype == NERFHIP_BF16) {
     CCHK(prepare_wgrad_bf16());
     CCHK(prepare_mlp_fwd_bf16(c.W, L.mode));
@@ -696,7 +698,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->dp_comm) nerfhip_dp_destroy(h);
   auto fr = [](void* p) { if (p) hipFree(p); };
-  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems);
+  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems); fr(h->d_amax);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
     fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_bwd_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.d_x3_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);

@@ -80,9 +80,11 @@ hipError_t launch_mlp_fwd_f16x3(const NetArgs& net, const void* stream_w, const 
                                 float* craw, int want_rgb, int nblk, int n_cu, const ActStore* st, hipStream_t stream);
 // mlp_bwd_f16x3.hip: backward-data pass of a training step with dtype f16x3 (reads/writes the fp32 activation store)
 hipError_t prepare_mlp_bwd_f16x3(int W, int mode);
+// amax: [D + 2] floats of this network, zeroed by the caller: slot l = largest |dY_l| written, slot D = largest
+// |d(head pre-activation)|, slot D + 1 = largest |d sigma|, |d craw| (for the weight-gradient kernel's operand scale)
 hipError_t launch_mlp_bwd_f16x3(const ActStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
                                 const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu,
-                                hipStream_t stream);
+                                float* amax, hipStream_t stream);
 // wgrad_bf16.hip: one slice of the sample axis of one product, operands in the bf16 store's operand layout
 struct WgradBfItem {
   const uint16_t* A;   // fragment (tile 0, first k-tile of the A rows, s = 0)
@@ -114,7 +116,13 @@ struct WgradItem {
   int32_t c0, c1;      // slice of the sample axis in 32-sample chunks
   int32_t wb_n;        // waves along B (1, 2 or 4); waves along A = 4 / wb_n
   int32_t shape;       // tiles per wave: AT * 16 + BT, each in {1, 2, 4}
+  // wgrad_f16x3.hip only: largest |element| of the buffer A lives in (device, written by mlp_bwd_f16x3.hip) and
+  // log2 of how many such elements an A value may be the sum of (the per-ray sums of the direction branch)
+  const float* amax;
+  int32_t amax_shift, pad_;
 };
+hipError_t prepare_wgrad_f16x3();
+hipError_t launch_wgrad_f16x3(const WgradItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s);
 hipError_t launch_wgrad_f32(const WgradItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s);
 hipError_t launch_ray_sum(const float* dh, int dh_rows, int rows, int64_t n, int S, float* out, int out_rows,
                           hipStream_t s);

@@ -59,6 +59,19 @@ __device__ __forceinline__ void store_tile16(float* dst, uint32_t voff, const fl
   if constexpr (R_ < 16) { store_reg<0, R_>(dst, voff, v[R_]); store_tile16<R_ + 1>(dst, voff, v); }
 }
 
+// largest value of a wave (DPP: row_shr 1/2/4/8, row_bcast 15/31; valid in lane 63; v >= 0, idle lanes read 0) into
+// a device slot: non-negative floats order like their bit patterns
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ void publish_max(Ring& rg, float* slot, float v, int lane) {
+  v = fmaxf(v, dpp_f<0x111, 0xf>(v)); v = fmaxf(v, dpp_f<0x112, 0xf>(v)); v = fmaxf(v, dpp_f<0x114, 0xf>(v));
+  v = fmaxf(v, dpp_f<0x118, 0xf>(v)); v = fmaxf(v, dpp_f<0x142, 0xa>(v)); v = fmaxf(v, dpp_f<0x143, 0xc>(v));
+  if (lane == 63) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, v));
+  rg.note(1);
+}
+
 // scale exponents stay inside [-kExpLim, kExpLim] so that no multiplier (2^(e_out - e_in - 6), 2^(-e_in - 6)) leaves fp32
 constexpr int kExpLim = 56;
 constexpr int kTargetLog2 = 5;   // the largest element of a sample's scaled gradient sits in [2^4, 2^5)
@@ -111,7 +124,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
                                                                        const float* __restrict__ d_sigma,
                                                                        const float* __restrict__ d_craw,
                                                                        const float* __restrict__ dirfeat, int64_t M, int S,
-                                                                       int nblk, int ntiles, ActStore st) {
+                                                                       int nblk, int ntiles, ActStore st,
+                                                                       float* __restrict__ amax_out) {
   constexpr int R = 32 * WT;
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   constexpr int Rh = 32 * HT;
@@ -157,6 +171,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
     const float amax0 = fmaxf(fmaxf(fabsf(dsg), fabsf(dc[0])), fmaxf(fabsf(dc[1]), fabsf(dc[2])));
     const int e0 = amax0 > 0.f ? clamp_exp(kTargetLog2 - 1 - floor_log2_bits(amax0)) : 0;
     const float s0 = pow2i(e0);
+    publish_max(rg, amax_out + D + 1, amax0, lane);
 
     // head gradients go out feature-major behind the hidden-layer rows: d sigma, then d craw^T (mlp_bwd.hip)
     float* const dhb = uniform_ptr_b(tile_block(st.dh, tix, Rh + 32));
@@ -187,6 +202,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       // k-step, whose operand is at e0, into the same accumulators)
       EpiGrad<HT> epi{dh, rg, dhb, svoff, bitsH, pow2i(-6), pow2i(-e0 - 6), 0.f};
       run_part<1, HT, false, true>(rg, 0u, SelOne{dcol}, epi);
+      publish_max(rg, amax_out + D, epi.amax * epi.kst, lane);
     } else {
       // mode 2: d q[3j+k] = d c[k] * Y_j(dir) (rows 0..26); mode 0: rows 0..2 = d c
       const float* Y = dirfeat + (int64_t)ray * 12;
@@ -200,6 +216,10 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       }
       store_tile16(dhb, svoff, v);
       rg.note(16);
+      float vm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vm = fmaxf(vm, fabsf(v[r]));
+      publish_max(rg, amax_out + D, vm, lane);
 #pragma unroll
       for (int p = 0; p < 8; ++p) split_into(dh.v[0][p / 4], p % 4, v[2 * p] * s0, v[2 * p + 1] * s0);
     }
@@ -211,6 +231,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       EpiGrad<WT> epi{g, rg, uniform_ptr_b(tile_block(st.dy + (int64_t)(D - 1) * R * Mp, tix, R)), svoff, bitsA, pow2i(-6),
                       pow2i(-e0 - 6), 0.f};
       run_part<2 * HT + 1, WT, false, true>(rg, 0u, SelHead<HT>{dh, dsig}, epi);
+      publish_max(rg, amax_out + D - 1, epi.amax * epi.kst, lane);
       amax_prev = fmaxf(epi.amax, __shfl_xor(epi.amax, 32));
       e_prev = e0;
     }
@@ -224,6 +245,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       EpiGrad<WT> epi{out, rg, uniform_ptr_b(tile_block(st.dy + (int64_t)(l - 1) * R * Mp, tix, R)), svoff, use,
                       pow2i(e_out - e_in - 6), pow2i(-e_in - 6), 0.f};
       run_part<2 * WT, WT, false, true>(rg, 0u, SelGrad<WT>{in}, epi);
+      publish_max(rg, amax_out + l - 1, epi.amax * epi.kst, lane);
       amax_prev = fmaxf(epi.amax, __shfl_xor(epi.amax, 32));
       e_prev = e_in;
       e_in = e_out;
@@ -240,12 +262,13 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
 
 template <int WT, int MODE>
 static hipError_t launch_bwd_one(const ActStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
-                                 const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu, hipStream_t stream) {
+                                 const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu, float* amax,
+                                 hipStream_t stream) {
   const size_t lds = (size_t)kRing * kBlkBytes;
   const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);
   const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kWaves);
   hipLaunchKernelGGL((mlp_bwd_f16x3_kernel<WT, MODE>), grid, block, lds, stream, net, (const char*)stream_w, d_sigma, d_craw,
-                     dirfeat, M, S, nblk, ntiles, st);
+                     dirfeat, M, S, nblk, ntiles, st, amax);
   return hipGetLastError();
 }
 
@@ -268,11 +291,11 @@ hipError_t prepare_mlp_bwd_f16x3(int W, int mode) {
 }
 
 hipError_t launch_mlp_bwd_f16x3(const ActStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
-                                const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu,
+                                const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu, float* amax,
                                 hipStream_t stream) {
   const int W = net.W, mode = net.mode;
 #define NH_X3B_LAUNCH(WT_, MODE_) \
-  return x3::launch_bwd_one<WT_, MODE_>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, n_cu, stream)
+  return x3::launch_bwd_one<WT_, MODE_>(st, net, stream_w, d_sigma, d_craw, dirfeat, M, S, nblk, n_cu, amax, stream)
   NH_X3B_CASES(NH_X3B_LAUNCH)
 #undef NH_X3B_LAUNCH
 }

@@ -55,8 +55,9 @@ def _rand_of(g):
 TRAIN_CASES = ["small_dir_train", "small_sh_train", "small_nodir_train", "small_flat_train", "small_opts_train"]
 
 
-# dtype "f16x3" trains with the split-f16 FORWARD kernel (fp32-grade activations written into the fp32 activation
-# store) and the fp32 backward / weight-gradient kernels: held to the fp32 gradient tests at the fp32 tolerances.
+# dtype "f16x3" trains on the split-f16 kernels throughout (forward writing fp32-grade activations into the fp32
+# activation store, backward-data with per-sample gradient scales, weight gradient with a per-tensor scale taken from
+# the backward kernel's running maxima): held to the fp32 gradient tests at the fp32 tolerances.
 # The W = 32 golden exists in fp32 only (the split-f16 kernels need W = 64, 128 or 256).
 TRAIN_DTYPES = [(cs, dt) for cs in TRAIN_CASES for dt in ("f32", "f16x3")
                 if not (dt == "f16x3" and H.CONFIGS[cs.rsplit("_", 1)[0]]["W"] == 32)]
@@ -145,7 +146,7 @@ def test_adam_step_matches_oracle(G):
 
 def test_f16x3_training_step_follows_the_fp32_one(G):
     """dtype "f16x3": split-f16 forward (activations, sign bits and encoding written into the fp32 activation store),
-    fp32 backward and weight gradient.  Same gradients as the all-fp32 step to within what a different summation order
+    split-f16 backward-data and weight-gradient kernels.  Same gradients as the all-fp32 step to within what a different summation order
     gives (2e-6 of the largest), and the render that follows uses the updated weights on both paths."""
     c = H.CONFIGS["small_dir"]
     g = load("small_dir_train")
