@@ -19,7 +19,8 @@ namespace x3 {
 
 constexpr int kWgRows = 256;                 // max rows per operand tile
 constexpr int kWgChunkFloats = kWgRows * 32; // one operand, one chunk: 256 rows x 32 samples
-constexpr int kWgBufBytes = 2 * kWgChunkFloats * 4;   // one buffer = A chunk | B chunk = 64 KiB
+constexpr int kWgSlotBytes = kWgChunkFloats * 4;      // one ring slot = one operand of one chunk = 32 KiB
+constexpr int kWgSlots = 5;                           // the whole 160 KiB of LDS
 
 template <int IMM>
 __device__ __forceinline__ void lds_read16(f32x4& d, uint32_t addr) {
@@ -40,29 +41,68 @@ __device__ __forceinline__ void tie_frags(f32x4 (&f)[NT]) {
 __device__ __forceinline__ void gatomic_add(float* p, float v) {
   __hip_atomic_fetch_add((__attribute__((address_space(1))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// s_waitcnt vmcnt(n) for a wave-uniform n in 0..8 (the count is an immediate)
+__device__ __forceinline__ void wait_vm_upto8(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+  }
+}
+__device__ __forceinline__ int ring_next(int s) { return s + 2 >= kWgSlots ? s + 2 - kWgSlots : s + 2; }   // slot of q + 2
 template <int N>
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N)); }
 
-// four fp32 samples -> dwords 2*HALF, 2*HALF+1 of an operand pair: hi = f16(v * k), lo = f16(v * k - hi)
+// four fp32 samples -> dwords 2*HALF, 2*HALF+1 of an operand pair: hi = f16(v * k), lo = f16(v * k - hi); in two
+// parts of four instructions each, so that they can be issued between MFMAs a few at a time
 template <int HALF>
-__device__ __forceinline__ void split4_by(Pair& p, const f32x4& v, float k) {
-  uint32_t h0, h1, l0, l1;
+__device__ __forceinline__ void split4_by_hi(Pair& p, const f32x4& v, float k) {
+  uint32_t h0, h1;
   asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h0) : "v"(v[0]), "s"(k));
   asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h0) : "v"(v[1]), "s"(k));
   asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h1) : "v"(v[2]), "s"(k));
   asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h1) : "v"(v[3]), "s"(k));
+  p.hi[2 * HALF] = h0; p.hi[2 * HALF + 1] = h1;
+}
+template <int HALF>
+__device__ __forceinline__ void split4_by_lo(Pair& p, const f32x4& v, float k) {
+  const uint32_t h0 = p.hi[2 * HALF], h1 = p.hi[2 * HALF + 1];
+  uint32_t l0, l1;
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v[0]), "s"(k), "v"(h0));
   asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v[1]), "s"(k), "v"(h0));
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v[2]), "s"(k), "v"(h1));
   asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v[3]), "s"(k), "v"(h1));
-  p.hi[2 * HALF] = h0; p.hi[2 * HALF + 1] = h1;
   p.lo[2 * HALF] = l0; p.lo[2 * HALF + 1] = l1;
 }
+// the same unscaled (f16x3_common.cuh: split_into)
 template <int HALF>
-__device__ __forceinline__ void split4(Pair& p, const f32x4& v) {   // unscaled
-  split_into(p, 2 * HALF, v[0], v[1]);
-  split_into(p, 2 * HALF + 1, v[2], v[3]);
+__device__ __forceinline__ void split4_hi(Pair& p, const f32x4& v) {
+  const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+  p.hi[2 * HALF] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v01, f16x2));
+  p.hi[2 * HALF + 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v23, f16x2));
 }
+template <int HALF>
+__device__ __forceinline__ void split4_lo(Pair& p, const f32x4& v) {
+  const uint32_t h0 = p.hi[2 * HALF], h1 = p.hi[2 * HALF + 1];
+  uint32_t l0, l1;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h0), "v"(v[0]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(h0), "v"(v[1]));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h1), "v"(v[2]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(h1), "v"(v[3]));
+  p.lo[2 * HALF] = l0; p.lo[2 * HALF + 1] = l1;
+}
+template <int N>
+using IC = std::integral_constant<int, N>;
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // One workgroup = one work entry; wave (wa, wb) owns A tiles [AT*wa, +AT) x B tiles [BT*wb, +BT).
 template <int AT, int BT>
@@ -96,20 +136,26 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
   float bs[AT];
 #pragma unroll
   for (int i = 0; i < AT; ++i) bs[i] = 0.f;
-  const bool do_bias = it.db != nullptr && wb == 0;
+  const bool do_bias = it.db != nullptr && wb == 0;   // every wave sums (no branch among the MFMAs); these flush
 
   // per-lane LDS byte addresses: row (row0 + li) of the A / B image + swizzled slot of k-group g
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem;
   const uint32_t sw = (uint32_t)((li >> 1) & 7);
   const uint32_t laneA = lds0 + (uint32_t)(a_row0 + li) * 128u;
-  const uint32_t laneB = lds0 + (uint32_t)kWgChunkFloats * 4u + (uint32_t)(b_row0 + li) * 128u;
+  const uint32_t laneB = lds0 + (uint32_t)(b_row0 + li) * 128u;
   uint32_t xoff[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) xoff[g] = 16u * ((uint32_t)(2 * g + h) ^ sw);
 
-  // Staging as in wgrad.hip: wave-instruction u of an operand covers rows 8u..8u+7; this wave issues u = wave + 4t.
+  // Staging: wave-instruction u of an operand covers rows 8u..8u+7 (image as in wgrad.hip); this wave issues
+  // u = wave + 4t.  The LDS is a ring of FIVE 32-KiB slots, each one operand of one chunk: operand-chunk
+  // q = 2j + (0: A, 1: B) of the entry's j-th chunk lives in slot q % 5.  While chunk j is used, chunk j+1 has landed or
+  // is landing and A of chunk j+2 is being requested into the slot B(j-1) left; the hand-over barrier in the middle of
+  // chunk j frees A(j)'s slot for B(j+2).  The wait in front of that barrier leaves A(j+2) -- the youngest DMAs of
+  // this wave -- in flight (a raw s_barrier: __syncthreads() would put vmcnt(0) in front of it).
   const int64_t a_step = (int64_t)it.a_stride * 32, b_step = (int64_t)it.b_stride * 32;   // floats per chunk
   const int nA8 = (it.a_rows + 7) >> 3, nB8 = (it.b_rows + 7) >> 3;
+  const int nPA = __builtin_amdgcn_readfirstlane(min(max((nA8 - wave + 3) >> 2, 0), 8));   // this wave's pieces of an A chunk
   uint32_t offA[8], offB[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -117,97 +163,111 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
     offA[t] = (uint32_t)((min(r, it.a_rows - 1) * 32 + 4 * sl) * 4);   // rows past the end repeat the last row (never stored)
     offB[t] = (uint32_t)((min(r, it.b_rows - 1) * 32 + 4 * sl) * 4);
   }
-  auto stage_t = [&](int c, int buf, int t) __attribute__((always_inline)) {   // pieces u = wave + 4t of both operands of chunk c
-    float* dst = smem + buf * 2 * kWgChunkFloats;
-    const char* ga = reinterpret_cast<const char*>(it.A + c * a_step);
-    const char* gb = reinterpret_cast<const char*>(it.B + c * b_step);
-    const int u = wave + 4 * t;
-    const uint32_t oa = t == 0 ? offA[0] : t == 1 ? offA[1] : t == 2 ? offA[2] : t == 3 ? offA[3] : t == 4 ? offA[4] : t == 5 ? offA[5] : t == 6 ? offA[6] : offA[7];
-    const uint32_t ob = t == 0 ? offB[0] : t == 1 ? offB[1] : t == 2 ? offB[2] : t == 3 ? offB[3] : t == 4 ? offB[4] : t == 5 ? offB[5] : t == 6 ? offB[6] : offB[7];
-    if (u < nA8) __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(ga + oa), NERFHIP_LPTR(dst + u * 256), 16, 0, 0);
-    if (u < nB8) __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(gb + ob), NERFHIP_LPTR(dst + kWgChunkFloats + u * 256), 16, 0, 0);
+  // piece T of operand OP (0: A, 1: B) of chunk c into ring slot `slot`
+  auto stage1 = [&](auto op, auto t_, int c, int slot) __attribute__((always_inline)) {
+    constexpr int OP = decltype(op)::value, T = decltype(t_)::value;
+    float* dst = smem + slot * kWgChunkFloats;
+    const char* g = OP == 0 ? reinterpret_cast<const char*>(it.A + c * a_step) : reinterpret_cast<const char*>(it.B + c * b_step);
+    const int u = wave + 4 * T;
+    if (u < (OP == 0 ? nA8 : nB8))
+      __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(g + (OP == 0 ? offA[T] : offB[T])), NERFHIP_LPTR(dst + u * 256), 16, 0, 0);
   };
-  auto stage = [&](int c, int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) stage_t(c, buf, t);
+  auto stage_all = [&](auto op, int c, int slot) __attribute__((always_inline)) {
+    static_for<8>([&](auto t_) __attribute__((always_inline)) { stage1(op, t_, c, slot); });
   };
-  stage(c0, 0);
-  if (c0 + 1 < c1) stage(c0 + 1, 1);
+  const int n = c1 - c0;
+  stage_all(IC<0>{}, c0, 0);
+  stage_all(IC<1>{}, c0, 1);
+  if (n > 1) { stage_all(IC<0>{}, c0 + 1, 2); stage_all(IC<1>{}, c0 + 1, 3); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ONE set of fragment registers: a k-group is converted into its half of the operand pairs as soon as it has
-  // landed, which frees the set for the next group's reads; those are issued in front of the k-step's MFMAs where there
-  // are any (odd groups), else their latency is exposed (twice per chunk, ~200 cycles of the ~6000 a chunk's bytes take
-  // to arrive).  A second set costs 32 registers that the 4 x 4 shape does not have: with it the compiler parks
-  // freshly loaded fragment registers in AGPRs while the loads are still in flight (scripts/check_inflight.py).
+  // The k-step being multiplied and the k-step being assembled: two sets of operand pairs.  A k-group (8 samples:
+  // one 16-byte fragment per tile) comes out of LDS into ONE set of fragment registers and is converted into its half
+  // of the pairs a few instructions at a time BETWEEN the MFMAs of the running k-step (back to back the conversions
+  // of a chunk take longer than its MFMAs: 7.1 k cycles per chunk against 3.1 k of matrix pipe, measured).
+  constexpr int NM = 3 * AT * BT;          // MFMAs of a k-step
+  constexpr int NH = 2 * (AT + BT);        // half-units of a k-group: (fragment, hi part | lo part)
+  // slots (positions behind MFMA m) of a block: group a is converted in [RA0, RA1), group b in [RB0, NM); the slots in
+  // front of either cover the latency of the group's fragment reads
+  constexpr int RA0 = NM / 6, RA1 = NM / 2, RB0 = NM / 2 + NM / 6;
+  Pair sA[2][AT], sB[2][BT];
   f32x4 fa[AT], fb[BT];
-  Pair opA[AT], opB[BT];   // the 16-sample k-step being assembled: k-groups 2s (dwords 0, 1) and 2s+1 (dwords 2, 3)
-  auto reads = [&](uint32_t bufoff, int g) __attribute__((always_inline)) {
-    read_frags<AT>(fa, laneA + bufoff + xoff[g]); read_frags<BT>(fb, laneB + bufoff + xoff[g]);
+  auto reads = [&](int sa, int sb, auto g_) __attribute__((always_inline)) {
+    constexpr int GI = decltype(g_)::value;
+    read_frags<AT>(fa, laneA + (uint32_t)sa * (uint32_t)kWgSlotBytes + xoff[GI]);
+    read_frags<BT>(fb, laneB + (uint32_t)sb * (uint32_t)kWgSlotBytes + xoff[GI]);
   };
   auto landed = [&]() __attribute__((always_inline)) { wait_lgkm<0>(); tie_frags<AT>(fa); tie_frags<BT>(fb); };
-  // the landed k-group -> half HALF of the operand pairs
-  auto convert = [&](auto half) __attribute__((always_inline)) {
-    constexpr int HALF = decltype(half)::value;
-    if (do_bias) {
-#pragma unroll
-      for (int i = 0; i < AT; ++i) bs[i] += (fa[i][0] + fa[i][1]) + (fa[i][2] + fa[i][3]);
-    }
-#pragma unroll
-    for (int i = 0; i < AT; ++i) split4_by<HALF>(opA[i], fa[i], G);
-#pragma unroll
-    for (int j = 0; j < BT; ++j) split4<HALF>(opB[j], fb[j]);
-    // the fragment registers are free from here on: keep the conversions in front of the next reads
-    asm volatile("" : "+v"(opA[0].hi), "+v"(opB[0].hi));
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto mfmas = [&]() __attribute__((always_inline)) {   // one 16-sample k-step: 3 AT BT MFMAs
-#pragma unroll
-    for (int i = 0; i < AT; ++i)
-#pragma unroll
-      for (int j = 0; j < BT; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(opA[i].hi), as_f16x8(opB[j].hi), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(opA[i].hi), as_f16x8(opB[j].lo), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(opA[i].lo), as_f16x8(opB[j].hi), acc[i][j], 0, 0, 0);
+  // half-unit K of the landed k-group -> k-group half HALF of operand set SET (bias sums ride on the A fragments)
+  auto half_unit = [&](auto k_, auto half_, auto set_) __attribute__((always_inline)) {
+    constexpr int K = decltype(k_)::value, HALF = decltype(half_)::value, SET = decltype(set_)::value;
+    constexpr int U = K >> 1, PART = K & 1;
+    if constexpr (U < AT) {
+      if constexpr (PART == 0) {
+        bs[U] += (fa[U][0] + fa[U][1]) + (fa[U][2] + fa[U][3]);
+        split4_by_hi<HALF>(sA[SET][U], fa[U], G);
+      } else {
+        split4_by_lo<HALF>(sA[SET][U], fa[U], G);
       }
-  };
-  using H0 = std::integral_constant<int, 0>;
-  using H1 = std::integral_constant<int, 1>;
-  auto burst = [&](int part, bool go, int pc, int pbuf) __attribute__((always_inline)) {   // staging pieces of chunk pc
-    if (go) {
-      if (part == 0) { stage_t(pc, pbuf, 0); stage_t(pc, pbuf, 1); }
-      if (part == 1) { stage_t(pc, pbuf, 2); stage_t(pc, pbuf, 3); stage_t(pc, pbuf, 4); }
-      if (part == 2) { stage_t(pc, pbuf, 5); stage_t(pc, pbuf, 6); stage_t(pc, pbuf, 7); }
+    } else {
+      if constexpr (PART == 0) split4_hi<HALF>(sB[SET][U - AT], fb[U - AT]);
+      else split4_lo<HALF>(sB[SET][U - AT], fb[U - AT]);
     }
   };
-  // One chunk: k-groups 0..3 = two k-steps.  With a chunk to follow, the hand-over to its buffer (DMA landed for
-  // everyone, first fragment reads) sits in front of the last k-step's MFMAs.
-  auto chunk = [&](int c, bool has_next) __attribute__((always_inline)) {
-    const uint32_t cur = (uint32_t)((c - c0) & 1) * (uint32_t)kWgBufBytes;
-    const bool more = c > c0 && c + 1 < c1;   // chunk c+1's parts 1 and 2 go into the buffer chunk c-1 used
-    const int nbuf = (c + 1 - c0) & 1;
-    landed(); convert(H0{});                  // group 0
-    reads(cur, 1);
-    burst(1, more, c + 1, nbuf);
-    landed(); convert(H1{});                  // group 1
-    reads(cur, 2);
-    burst(2, more, c + 1, nbuf);
-    mfmas();                                  // k-step 0, over the reads of group 2
-    landed(); convert(H0{});                  // group 2
-    reads(cur, 3);
-    landed(); convert(H1{});                  // group 3: every wave is done READING this buffer
-    if (has_next) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c+1 must have landed for all
-      __syncthreads();
-      burst(0, c + 2 < c1, c + 2, (c - c0) & 1);
-      reads(cur ^ (uint32_t)kWgBufBytes, 0);
-    }
-    mfmas();                                  // k-step 1, over the first reads of the next chunk
+  // One block = the MFMAs of the k-step in operand set SET.  With CONV, k-groups GA and GA+1 of the chunk in ring slots
+  // (ra, rb) are read and converted into set 1-SET between them, and, if `go`, operand OP of chunk cs is requested
+  // into ring slot ss: pieces 0..3 behind the first MFMAs, 4..7 behind those of the second half.
+  auto block = [&](auto set_, auto conv_, auto ga_, int ra, int rb, auto op_, bool go, int cs, int ss) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_)::value, GA = decltype(ga_)::value;
+    constexpr bool CONV = decltype(conv_)::value != 0;
+    if constexpr (CONV) reads(ra, rb, IC<GA>{});
+    static_for<NM>([&](auto m_) __attribute__((always_inline)) {
+      constexpr int M = decltype(m_)::value, I = M / (3 * BT), J = (M / 3) % BT, T = M % 3;
+      acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(T == 2 ? sA[SET][I].lo : sA[SET][I].hi),
+                                                         as_f16x8(T == 1 ? sB[SET][J].lo : sB[SET][J].hi), acc[I][J], 0, 0, 0);
+      if constexpr (CONV) {
+        static_for<8>([&](auto t_) __attribute__((always_inline)) {
+          constexpr int T8 = decltype(t_)::value;
+          constexpr int slot = T8 < 4 ? (T8 < NM - 1 ? T8 : NM - 1) : (RA1 + T8 - 4 < NM - 1 ? RA1 + T8 - 4 : NM - 1);
+          if constexpr (slot == M) { if (go) stage1(op_, t_, cs, ss); }
+        });
+        if constexpr (M == RA0) landed();
+        static_for<NH>([&](auto k_) __attribute__((always_inline)) {
+          if constexpr (RA0 + decltype(k_)::value * (RA1 - RA0) / NH == M) half_unit(k_, IC<0>{}, IC<1 - SET>{});
+        });
+        if constexpr (M == RA1 - 1) reads(ra, rb, IC<GA + 1>{});
+        if constexpr (M == RB0) landed();
+        static_for<NH>([&](auto k_) __attribute__((always_inline)) {
+          if constexpr (RB0 + decltype(k_)::value * (NM - RB0) / NH == M) half_unit(k_, IC<1>{}, IC<1 - SET>{});
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
-  reads(0u, 0);
-  for (int c = c0; c < c1 - 1; ++c) chunk(c, true);
-  chunk(c1 - 1, false);   // peeled: no fragment read is in flight when the loop is left
+  // the first k-step of the entry is assembled with nothing to hide behind
+  reads(0, 1, IC<0>{});
+  landed();
+  static_for<NH>([&](auto k_) __attribute__((always_inline)) { half_unit(k_, IC<0>{}, IC<0>{}); });
+  reads(0, 1, IC<1>{});
+  landed();
+  static_for<NH>([&](auto k_) __attribute__((always_inline)) { half_unit(k_, IC<1>{}, IC<0>{}); });
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    int sa = 0, sb = 1, pb = 4;   // slots of A(j), B(j), B(j-1)
+    for (int j = 0;; ++j) {         // one copy of every converting block; no fragment read in flight at the exit or the back edge
+      const bool go = j + 2 < n;
+      block(IC<0>{}, IC<1>{}, IC<2>{}, sa, sb, IC<0>{}, go, c0 + j + 2, pb);      // k-step (j, 0); groups (j, 2), (j, 3); A(j+2)
+      if (j == n - 1) break;
+      // hand-over: chunk j+1 has landed for all and every wave is done reading chunk j
+      wait_vm_upto8(go ? nPA : 0);
+      __builtin_amdgcn_s_barrier();
+      const int nsa = ring_next(sa), nsb = ring_next(sb);
+      block(IC<1>{}, IC<1>{}, IC<0>{}, nsa, nsb, IC<1>{}, go, c0 + j + 2, sa);    // k-step (j, 1); groups (j+1, 0), (j+1, 1); B(j+2)
+      pb = sb; sa = nsa; sb = nsb;
+    }
+    block(IC<1>{}, IC<0>{}, IC<0>{}, 0, 0, IC<0>{}, false, 0, 0);                 // the entry's last k-step
+  }
   // combine the sample-axis slices: fp32 atomics, 128 contiguous bytes per lane half per instruction
 #pragma unroll
   for (int i = 0; i < AT; ++i) {
@@ -231,15 +291,25 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
   }
 }
 
+#ifdef X3W_STAMPS   // diagnostic build only (scripts/x3w_stamps.py): cycles of every work entry, span of every workgroup
+__device__ unsigned long long g_x3w_entry[8192 * 2];
+__device__ unsigned long long g_x3w_span[1024 * 2];
+#endif
 // Persistent workgroup b works through the entries first[b] .. first[b+1]-1 (host: train_impl.inc).
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgradItem* __restrict__ items,
                                                              const int32_t* __restrict__ first) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers x (A chunk | B chunk)
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // ring of 5 operand-chunk slots
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int e0 = first[blockIdx.x], e1 = first[blockIdx.x + 1];
+#ifdef X3W_STAMPS
+  if (threadIdx.x == 0) g_x3w_span[2 * blockIdx.x] = wall_clock64();
+#endif
   for (int e = e0; e < e1; ++e) {
     const WgradItem it = items[e];
     if (it.c0 >= it.c1) continue;
+#ifdef X3W_STAMPS
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
     switch (it.shape) {   // (tiles per wave along A) * 16 + (tiles per wave along B), chosen by the host
       case 0x44: wgrad_body<4, 4>(it, smem, wave, lane); break;
       case 0x42: wgrad_body<4, 2>(it, smem, wave, lane); break;
@@ -252,20 +322,36 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgradItem* __
       default:   wgrad_body<1, 1>(it, smem, wave, lane); break;
     }
     __syncthreads();   // every wave is done reading the LDS buffers before the next entry stages into them
+#ifdef X3W_STAMPS
+    if (threadIdx.x == 0) {
+      g_x3w_entry[2 * e] = __builtin_amdgcn_s_memtime() - t0;
+      g_x3w_entry[2 * e + 1] = ((unsigned long long)it.a_rows << 48) | ((unsigned long long)it.b_rows << 32) | (unsigned long long)(it.c1 - it.c0) << 12 | blockIdx.x;
+    }
+#endif
   }
+#ifdef X3W_STAMPS
+  if (threadIdx.x == 0) g_x3w_span[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 }  // namespace x3
 
-// once per device, with that device current (nerfhip_create): allow the kernel its 128 KiB of dynamic LDS
+// once per device, with that device current (nerfhip_create): allow the kernel its 160 KiB of dynamic LDS
 hipError_t prepare_wgrad_f16x3() {
   return hipFuncSetAttribute((const void*)x3::wgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)((size_t)4 * x3::kWgChunkFloats * sizeof(float)));
+                             x3::kWgSlots * x3::kWgSlotBytes);
 }
 
+#ifdef X3W_STAMPS
+extern "C" int nerfhip_debug_x3w_stamps(unsigned long long* entry, unsigned long long* span) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(entry, HIP_SYMBOL(x3::g_x3w_entry), sizeof(unsigned long long) * 8192 * 2) != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(span, HIP_SYMBOL(x3::g_x3w_span), sizeof(unsigned long long) * 1024 * 2) != hipSuccess;
+}
+#endif
 hipError_t launch_wgrad_f16x3(const WgradItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s) {
   if (ngroups <= 0) return hipSuccess;
-  const size_t lds = (size_t)4 * x3::kWgChunkFloats * sizeof(float);  // 128 KiB
+  const size_t lds = (size_t)x3::kWgSlots * x3::kWgSlotBytes;  // 160 KiB
   hipLaunchKernelGGL(x3::wgrad_f16x3_kernel, dim3(ngroups), dim3(256), lds, s, d_items, d_first);
   return hipGetLastError();
 }
