@@ -60,16 +60,17 @@ __device__ __forceinline__ void store_tile16(float* dst, uint32_t voff, const fl
 }
 
 // largest value of a wave (DPP: row_shr 1/2/4/8, row_bcast 15/31; valid in lane 63; v >= 0, idle lanes read 0) into
-// a device slot: non-negative floats order like their bit patterns
+// the workgroup's slot in LDS: non-negative floats order like their bit patterns.  The workgroup publishes its slots
+// to device memory ONCE, when it has run out of tiles: a global atomic per wave and part (330 000 per step on ten
+// addresses) sat in the in-order vmcnt queue in front of the ring's LDS-DMA and cost 1.25 ms of the kernel's 4.4.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ void publish_max(Ring& rg, float* slot, float v, int lane) {
+__device__ __forceinline__ void publish_max(unsigned* slot, float v, int lane) {
   v = fmaxf(v, dpp_f<0x111, 0xf>(v)); v = fmaxf(v, dpp_f<0x112, 0xf>(v)); v = fmaxf(v, dpp_f<0x114, 0xf>(v));
   v = fmaxf(v, dpp_f<0x118, 0xf>(v)); v = fmaxf(v, dpp_f<0x142, 0xa>(v)); v = fmaxf(v, dpp_f<0x143, 0xc>(v));
-  if (lane == 63) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, v));
-  rg.note(1);
+  if (lane == 63) atomicMax(slot, __builtin_bit_cast(unsigned, v));
 }
 
 // scale exponents stay inside [-kExpLim, kExpLim] so that no multiplier (2^(e_out - e_in - 6), 2^(-e_in - 6)) leaves fp32
@@ -112,13 +113,21 @@ struct EpiGrad {
     const float v0 = __builtin_bit_cast(float, __builtin_bit_cast(int, x0) & m0);
     const float v1 = __builtin_bit_cast(float, __builtin_bit_cast(int, x1) & m1);
     amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+#ifndef X3B_NOSTORE
     store_reg<OT_IDX, 2 * P>(dst, voff, v0 * kst);
     store_reg<OT_IDX, 2 * P + 1>(dst, voff, v1 * kst);
     rg.note(2);
+#endif
     split_by_into(out.v[OT_IDX][P / 4], P % 4, v0, v1, kx);
   }
 };
 
+#ifdef X3B_STAMPS   // diagnostic build only (scripts/x3b_stamps.py): cycle stamps of one wave's 4th tile
+__device__ unsigned long long g_x3b_stamps[32];
+#define X3B_STAMP(i) do { if (blockIdx.x == 8 && wave == 1 && tile == blockIdx.x + 3 * (int)gridDim.x && lane == 0) g_x3b_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X3B_STAMP(i)
+#endif
 template <int WT, int MODE>
 __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs net, const char* __restrict__ stream,
                                                                        const float* __restrict__ d_sigma,
@@ -131,6 +140,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
   constexpr int Rh = 32 * HT;
   constexpr int NW = (WT + 1) / 2, NWH = (HT + 1) / 2;
   extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring only
+  __shared__ unsigned s_amax[kMaxD + 2];   // largest |gradient| bits per amax slot, over this workgroup's tiles
 
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,10 +155,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
   rg.lane = lane;
   rg.voff = (uint32_t)(wave * (kBlkBytes / kWaves) + lane * 16);
   rg.nblk = nblk;
+  if (tid < kMaxD + 2) s_amax[tid] = 0u;   // visible behind the barrier in start()
   rg.start();
   const uint32_t svoff = tile_voff(lane);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    X3B_STAMP(0);
     const int m = tile * kTileSamples + wave * 32 + li;   // host guarantees M < 2^31
     const bool valid = m < (int)M;
     const int mc = valid ? m : (int)M - 1;
@@ -157,8 +169,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
     // sign bits of a layer: 4 words per lane (word w at + w * Mpad); slot D = the colour hidden layer
     auto load_bits = [&](uint32_t (&b)[4], int slot, int nw) __attribute__((always_inline)) {
 #pragma unroll
+#ifdef X3B_NOBITS
+      for (int w = 0; w < 4; ++w) b[w] = 0xffffffffu;
+#else
       for (int w = 0; w < 4; ++w) b[w] = w < nw ? __builtin_nontemporal_load(mask_ptr(st.mask, slot, h, w, Mp, m)) : 0u;
       rg.note(nw);
+#endif
     };
     uint32_t bitsA[4], bitsB[4], bitsH[4];
     if constexpr (MODE == 1) load_bits(bitsH, D, NWH);
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
     const float amax0 = fmaxf(fmaxf(fabsf(dsg), fabsf(dc[0])), fmaxf(fabsf(dc[1]), fabsf(dc[2])));
     const int e0 = amax0 > 0.f ? clamp_exp(kTargetLog2 - 1 - floor_log2_bits(amax0)) : 0;
     const float s0 = pow2i(e0);
-    publish_max(rg, amax_out + D + 1, amax0, lane);
+    publish_max(s_amax + D + 1, amax0, lane);
 
     // head gradients go out feature-major behind the hidden-layer rows: d sigma, then d craw^T (mlp_bwd.hip)
     float* const dhb = uniform_ptr_b(tile_block(st.dh, tix, Rh + 32));
@@ -193,6 +209,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       split_into(dcol, 1, dc[2] * s0, 0.f);
     }
 
+    X3B_STAMP(1);
     // ---- d(head pre-activation), scale e0
     GradRegs<HT> dh;
     float amax_prev;   // max |accumulator| of the part just finished (both lane halves), its input scale in e_prev
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       // k-step, whose operand is at e0, into the same accumulators)
       EpiGrad<HT> epi{dh, rg, dhb, svoff, bitsH, pow2i(-6), pow2i(-e0 - 6), 0.f};
       run_part<1, HT, false, true>(rg, 0u, SelOne{dcol}, epi);
-      publish_max(rg, amax_out + D, epi.amax * epi.kst, lane);
+      publish_max(s_amax + D, epi.amax * epi.kst, lane);
     } else {
       // mode 2: d q[3j+k] = d c[k] * Y_j(dir) (rows 0..26); mode 0: rows 0..2 = d c
       const float* Y = dirfeat + (int64_t)ray * 12;
@@ -219,11 +236,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       float vm = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) vm = fmaxf(vm, fabsf(v[r]));
-      publish_max(rg, amax_out + D, vm, lane);
+      publish_max(s_amax + D, vm, lane);
 #pragma unroll
       for (int p = 0; p < 8; ++p) split_into(dh.v[0][p / 4], p % 4, v[2 * p] * s0, v[2 * p + 1] * s0);
     }
 
+    X3B_STAMP(2);
     // ---- head backward: d feat = Wf^T . dh + w_sigma . d sigma, masked by the last trunk layer's ReLU
     GradRegs<WT> g, gn;
     {
@@ -231,10 +249,11 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       EpiGrad<WT> epi{g, rg, uniform_ptr_b(tile_block(st.dy + (int64_t)(D - 1) * R * Mp, tix, R)), svoff, bitsA, pow2i(-6),
                       pow2i(-e0 - 6), 0.f};
       run_part<2 * HT + 1, WT, false, true>(rg, 0u, SelHead<HT>{dh, dsig}, epi);
-      publish_max(rg, amax_out + D - 1, epi.amax * epi.kst, lane);
+      publish_max(s_amax + D - 1, epi.amax * epi.kst, lane);
       amax_prev = fmaxf(epi.amax, __shfl_xor(epi.amax, 32));
       e_prev = e0;
     }
+    X3B_STAMP(3);
     // ---- trunk, last layer first: dY_{l-1} = ReLU'_{l-1} . (W_l^T . dY_l); two layers per trip (g -> gn -> g)
     int e_in = e0;   // scale of the operands the next part consumes
     auto layer = [&](int l, const GradRegs<WT>& in, GradRegs<WT>& out, const uint32_t (&use)[4], uint32_t (&fetch)[4])
@@ -245,10 +264,11 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
       EpiGrad<WT> epi{out, rg, uniform_ptr_b(tile_block(st.dy + (int64_t)(l - 1) * R * Mp, tix, R)), svoff, use,
                       pow2i(e_out - e_in - 6), pow2i(-e_in - 6), 0.f};
       run_part<2 * WT, WT, false, true>(rg, 0u, SelGrad<WT>{in}, epi);
-      publish_max(rg, amax_out + l - 1, epi.amax * epi.kst, lane);
+      publish_max(s_amax + l - 1, epi.amax * epi.kst, lane);
       amax_prev = fmaxf(epi.amax, __shfl_xor(epi.amax, 32));
       e_prev = e_in;
       e_in = e_out;
+      X3B_STAMP(3 + D - l);
     };
     int l = D - 1;
     for (; l >= 2; l -= 2) {
@@ -258,6 +278,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
     if (l >= 1) layer(l, g, gn, bitsB, bitsA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+  __syncthreads();
+  if (tid < D + 2 && s_amax[tid] != 0u) atomicMax(reinterpret_cast<unsigned*>(amax_out) + tid, s_amax[tid]);
 }
 
 template <int WT, int MODE>
@@ -285,11 +307,17 @@ static hipError_t launch_bwd_one(const ActStore& st, const NetArgs& net, const v
 // once per device, with that device current (nerfhip_create)
 hipError_t prepare_mlp_bwd_f16x3(int W, int mode) {
 #define NH_X3B_PREP(WT_, MODE_) \
-  return hipFuncSetAttribute((const void*)x3::mlp_bwd_f16x3_kernel<WT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  return hipFuncSetAttribute((const void*)x3::mlp_bwd_f16x3_kernel<WT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, x3::kRing * x3::kBlkBytes)
   NH_X3B_CASES(NH_X3B_PREP)
 #undef NH_X3B_PREP
 }
 
+#ifdef X3B_STAMPS
+extern "C" int nerfhip_debug_x3b_stamps(unsigned long long* out) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(x3::g_x3b_stamps), sizeof(unsigned long long) * 32) != hipSuccess;
+}
+#endif
 hipError_t launch_mlp_bwd_f16x3(const ActStore& st, const NetArgs& net, const void* stream_w, const float* d_sigma,
                                 const float* d_craw, const float* dirfeat, int64_t M, int S, int nblk, int n_cu, float* amax,
                                 hipStream_t stream) {
