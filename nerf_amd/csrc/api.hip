@@ -371,10 +371,12 @@ int repack(nerfhip* h) {
   for (int i = 0; i < h->nnets; ++i) {
     Net& n = h->nets[i];
     const float* p = h->d_params + n.param_off;
-    HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));   // fp32 tile images
-    HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
+    if (h->cfg.dtype != NERFHIP_F16X3) {   // fp32 tile images: only the fp32 MFMA kernels read them
+      HIPCHK(h, launch_pack_chunks(p, n.d_fwd_desc, (int)n.fwd_desc.size(), n.d_wpack_fwd, h->stream));
+      HIPCHK(h, launch_pack_chunks(p, n.d_bwd_desc, (int)n.bwd_desc.size(), n.d_wpack_bwd, h->stream));
+    }
     HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
-    if (h->cfg.dtype == NERFHIP_F16X3) {   // + the render kernel's pair streams (training stays on the fp32 kernels)
+    if (h->cfg.dtype == NERFHIP_F16X3) {   // the split-f16 kernels' pair streams (forward, density-only, backward)
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->stream));
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, h->stream));
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_bwd_desc, (int)n.x3_bwd.size(), n.d_x3_bwd, h->stream));

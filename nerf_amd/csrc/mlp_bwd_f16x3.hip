@@ -113,11 +113,9 @@ struct EpiGrad {
     const float v0 = __builtin_bit_cast(float, __builtin_bit_cast(int, x0) & m0);
     const float v1 = __builtin_bit_cast(float, __builtin_bit_cast(int, x1) & m1);
     amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
-#ifndef X3B_NOSTORE
     store_reg<OT_IDX, 2 * P>(dst, voff, v0 * kst);
     store_reg<OT_IDX, 2 * P + 1>(dst, voff, v1 * kst);
     rg.note(2);
-#endif
     split_by_into(out.v[OT_IDX][P / 4], P % 4, v0, v1, kx);
   }
 };
@@ -169,12 +167,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_bwd_f16x3_kernel(NetArgs n
     // sign bits of a layer: 4 words per lane (word w at + w * Mpad); slot D = the colour hidden layer
     auto load_bits = [&](uint32_t (&b)[4], int slot, int nw) __attribute__((always_inline)) {
 #pragma unroll
-#ifdef X3B_NOBITS
-      for (int w = 0; w < 4; ++w) b[w] = 0xffffffffu;
-#else
       for (int w = 0; w < 4; ++w) b[w] = w < nw ? __builtin_nontemporal_load(mask_ptr(st.mask, slot, h, w, Mp, m)) : 0u;
       rg.note(nw);
-#endif
     };
     uint32_t bitsA[4], bitsB[4], bitsH[4];
     if constexpr (MODE == 1) load_bits(bitsH, D, NWH);
