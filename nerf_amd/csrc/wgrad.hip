@@ -235,14 +235,24 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
 }
 
 // Persistent workgroup b works through the entries first[b] .. first[b+1]-1 (host: train_impl.inc).
+#ifdef WGF_STAMPS   // diagnostic build only (scripts/x3w_stamps.py <lib> f32): cycles of every work entry, span of every workgroup
+__device__ unsigned long long g_wgf_entry[8192 * 2];
+__device__ unsigned long long g_wgf_span[1024 * 2];
+#endif
 __global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __restrict__ items,
                                                            const int32_t* __restrict__ first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 buffers x (A chunk | B chunk)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int e0 = first[blockIdx.x], e1 = first[blockIdx.x + 1];
+#ifdef WGF_STAMPS
+  if (threadIdx.x == 0) g_wgf_span[2 * blockIdx.x] = wall_clock64();
+#endif
   for (int e = e0; e < e1; ++e) {
     const WgradItem it = items[e];
     if (it.c0 >= it.c1) continue;
+#ifdef WGF_STAMPS
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
     switch (it.shape) {   // (tiles per wave along A) * 16 + (tiles per wave along B), chosen by the host
       case 0x44: wgrad_body<4, 4>(it, smem, wave, lane); break;
       case 0x42: wgrad_body<4, 2>(it, smem, wave, lane); break;
@@ -255,8 +265,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __re
       default:   wgrad_body<1, 1>(it, smem, wave, lane); break;
     }
     __syncthreads();   // every wave is done reading the LDS buffers before the next entry stages into them
+#ifdef WGF_STAMPS
+    if (threadIdx.x == 0) {
+      g_wgf_entry[2 * e] = __builtin_amdgcn_s_memtime() - t0;
+      g_wgf_entry[2 * e + 1] = ((unsigned long long)it.a_rows << 48) | ((unsigned long long)it.b_rows << 32) | (unsigned long long)(it.c1 - it.c0) << 12 | blockIdx.x;
+    }
+#endif
   }
+#ifdef WGF_STAMPS
+  if (threadIdx.x == 0) g_wgf_span[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
+#ifdef WGF_STAMPS
+extern "C" int nerfhip_debug_wgf_stamps(unsigned long long* entry, unsigned long long* span) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(entry, HIP_SYMBOL(g_wgf_entry), sizeof(unsigned long long) * 8192 * 2) != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(span, HIP_SYMBOL(g_wgf_span), sizeof(unsigned long long) * 1024 * 2) != hipSuccess;
+}
+#endif
 
 // d(dirvec)^T(j, ray) = sum over the ray's samples of dh(j, ray*S + s); both buffers tile-major (common.h).
 // One workgroup per ray; a wave-load covers 8 rows x 32 samples of one tile (16 B per lane, 1 KiB per instruction),

@@ -1,5 +1,5 @@
 """Diagnostic: per-entry cycles and per-workgroup spans of the split-f16 weight-gradient kernel, from a library built
-with -DX3W_STAMPS (python scripts/x3w_stamps.py <library>).  Prints cycles per chunk by product kind and the spread of
+with -DX3W_STAMPS (python scripts/x3w_stamps.py <library>), or of the fp32 one built with -DWGF_STAMPS (... <library> f32).  Prints cycles per chunk by product kind and the spread of
 the workgroups' finishing times (what the equal-share cost model in train_impl.inc is fitted to)."""
 import sys, os, ctypes as C, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,8 @@ import helpers as H
 from nerf_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from nerf_amd import NerfBlock, NerfConfig
-c = dict(H.CONFIGS["full"], dtype="f16x3")
+dtype = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
+c = dict(H.CONFIGS["full"], dtype=dtype)
 nT = 4096
 tr = NerfBlock(NerfConfig.from_dict(dict(c, maxRays=nT)))
 tr.init_params(1)
@@ -21,7 +22,8 @@ for _ in range(4):
 tr.synchronize()
 lib = C.CDLL(_lib.LIB_PATH)
 ent = np.zeros(8192 * 2, np.uint64); span = np.zeros(1024 * 2, np.uint64)
-assert lib.nerfhip_debug_x3w_stamps(ent.ctypes.data_as(C.c_void_p), span.ctypes.data_as(C.c_void_p)) == 0
+fn = lib.nerfhip_debug_x3w_stamps if dtype == "f16x3" else lib.nerfhip_debug_wgf_stamps
+assert fn(ent.ctypes.data_as(C.c_void_p), span.ctypes.data_as(C.c_void_p)) == 0
 ent = ent.reshape(-1, 2); span = span.reshape(-1, 2)[:256].astype(np.int64)
 kinds = collections.defaultdict(list)
 for cyc, info in ent:
@@ -56,3 +58,12 @@ for x in range(8):
     sel = rows[rows[:, 0].astype(int) % 8 == x]
     print(f"  xcd {x}: {len(sel):3d} entries, mean cycles/chunk {sel[:, 2].mean():.0f}; busy us of its workgroups: mean {dur[x::8].mean():.0f} max {dur[x::8].max():.0f}")
 print("busy us by workgroup (every 8th):", " ".join(f"{v:.0f}" for v in dur[::8]))
+# the slowest and fastest workgroups and what they ran
+by_wg = collections.defaultdict(list)
+for cyc, info in ent:
+    info = int(info)
+    if info == 0: continue
+    by_wg[info & 0xfff].append((info >> 48, (info >> 32) & 0xffff, (info >> 12) & 0xfffff, int(cyc)))
+order = np.argsort(dur)
+for w in list(order[:4]) + list(order[-6:]):
+    print(f"  wg {w:3d} busy {dur[w]:.0f} us:", "; ".join(f"{a}x{b} {n} chunks {c / 1e3:.0f}k cyc" for a, b, n, c in by_wg[int(w)]))
