@@ -290,15 +290,15 @@ def main():
                     "kernel_ms_per_step": {k: round(v[0] / nsteps, 4) for k, v in ks.items()},
                     "kernel_tflops": {k: round(v[1] / max(v[0], 1e-9) / 1e9, 1) for k, v in ks.items()}}
 
-        # ---- dtype f16x3 training: split-f16 forward and backward-data kernels (fp32-grade: held to the fp32 gradient
-        # tests at the fp32 tolerances, tests/test_gpu_train.py), fp32 weight gradient; own dtype label
+        # ---- dtype f16x3 training: split-f16 forward, backward-data and weight-gradient kernels (fp32-grade: held to the
+        # fp32 gradient tests at the fp32 tolerances, tests/test_gpu_train.py); own dtype label
         train_f16x3 = None
         if args.dtype == "f32" and not args.no_bf16_train:
             tx = NerfBlock(NerfConfig.from_dict(dict(base, maxRays=B, dtype="f16x3")))
             tx.set_stream(stream)
             tx.init_params(7)
             train_f16x3 = timed_train(tx, t_o, t_d, t_b, t_l, args.steps, "f16x3")
-            train_f16x3["metric"] = "rays/sec (train step, split-f16 MFMA forward/backward, fp32-grade)"
+            train_f16x3["metric"] = "rays/sec (train step, split-f16 MFMA forward/backward/weight gradient, fp32-grade)"
             tx.close()
             note("f16x3 train leg done")
 

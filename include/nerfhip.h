@@ -37,9 +37,10 @@ enum {
 };
 
 /* MFMA operand type of the MLP kernels.  F32: v_mfma_f32_32x32x2_f32 everywhere (the parity mode).  BF16: bf16 operands,
- * fp32 accumulation (renders within 1e-2 abs).  F16X3: RENDER with split-f16 operands (every operand = hi + lo, two f16
- * halves; three f16 MFMAs per product, fp32 accumulation; weights must stay below 1023 in magnitude): fp32-grade results -- held to the same parity tests and tolerances as F32 --
- * at about 3x the F32 render rate; training calls on such a handle run the F32 kernels. */
+ * fp32 accumulation (renders within 1e-2 abs).  F16X3: split-f16 operands (every operand = hi + lo, two f16 halves; three
+ * f16 MFMAs per product, fp32 accumulation; weights must stay below 1023 in magnitude) in the render AND the training
+ * kernels: fp32-grade results -- held to the same parity tests and tolerances as F32 -- at about 3x the F32 render rate
+ * and 2.3x the F32 training rate; parameters, gradients and optimizer state stay fp32. */
 enum { NERFHIP_F32 = 0, NERFHIP_BF16 = 1, NERFHIP_F16X3 = 2 };
 
 /* Mirrors the arithmetic-relevant fields of nerf/nerfConfig.scala:20-43 (same meaning, same order),
@@ -65,7 +66,7 @@ typedef struct nerfhip_config {
   /* ---- build extensions ---- */
   int32_t device;            /* HIP device ordinal (nerfConfig.device, :7) */
   int32_t dtype;             /* NERFHIP_F32 | NERFHIP_BF16 | NERFHIP_F16X3 : MFMA operand type of the MLP (F16X3: split-f16
-                              * render kernels at fp32 accuracy, weights |w| < 1023; training runs the fp32 kernels) */
+                              * render and training kernels at fp32 accuracy, weights |w| < 1023) */
   uint64_t seed;             /* Philox key for perturb / raw-noise / init */
   int32_t max_rays;          /* largest n any call will pass (workspace is sized once from it) */
   int32_t reserved;

@@ -17,5 +17,6 @@ echo stats done
 cd $R
 bash scripts/pmc_train.sh bf16 ${TAG}_bf16
 bash scripts/pmc_train.sh f32 ${TAG}_f32
+bash scripts/pmc_train.sh f16x3 ${TAG}_f16x3train
 bash scripts/hbm_prof.sh ${TAG}
 bash scripts/x3_prof.sh f16x3 ${TAG}_f16x3
