@@ -35,7 +35,7 @@ def _frame(G, blk, hw=400):
     return ro, rd, bd
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16"])
 def test_frame_split_and_permutation_invariance(G, dtype):
     import torch
     c = H.CONFIGS["full"]
@@ -58,7 +58,8 @@ def test_frame_split_and_permutation_invariance(G, dtype):
     blk.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 2e-5)])
+# f16x3: the weight-gradient operand scale comes from the batch's largest gradient, so shards and whole batch round differently
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("f16x3", 5e-5), ("bf16", 2e-5)])
 def test_batch_gradient_is_mean_of_shard_gradients(G, dtype, tol):
     c = H.CONFIGS["full"]
     B = 4096

@@ -79,13 +79,14 @@ def test_shipped_config_render(G, shipped, dtype):
     blk.close()
 
 
-def test_shipped_config_train_backward_f32(G, shipped):
-    """forward(training, noise on the raw density) + L2 + backward with the noise tensor passed in: loss 1e-4 relative,
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_shipped_config_train_backward_f32(G, shipped, dtype):
+    """(fp32 bars; dtype f16x3 = the split-f16 training kernels, held to the same ones)  forward(training, noise on the raw density) + L2 + backward with the noise tensor passed in: loss 1e-4 relative,
     whole gradient < 1e-3 relative L2 of the oracle's, per tensor norm 1e-2; and the library-drawn noise path runs the
     same batch to a finite loss of the same size."""
     s = shipped
     c = s["c"]
-    blk = G.make_block(c, max_rays=s["n"])
+    blk = G.make_block(c, max_rays=s["n"], dtype=dtype)
     blk.set_params(s["params"])
     lf, lc = blk.train_backward(s["ro"], s["rd"], s["b"], s["rd"], s["label"], rand={"noise_f": s["noise"]})
     gr, rg = blk.get_grads(), s["tr"]["grads"]
@@ -129,12 +130,13 @@ def config5():
     return dict(c=c, n=n, ro=ro, rd=rd, b=b, label=label, params=params)
 
 
-def test_config5_training_f32(G, config5):
-    """configs[4] shapes in fp32 against the oracle: losses 1e-3 relative, whole gradient < 2e-2, per-tensor norms 1e-2
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_config5_training_f32(G, config5, dtype):
+    """configs[4] shapes in fp32 (and on the fp32-grade split-f16 kernels) against the oracle: losses 1e-3 relative, whole gradient < 2e-2, per-tensor norms 1e-2
     (the bars of test_gradients_full: end to end, one fine depth that differs by an ulp moves one sample)."""
     s = config5
     c = s["c"]
-    blk = G.make_block(c, max_rays=s["n"])
+    blk = G.make_block(c, max_rays=s["n"], dtype=dtype)
     blk.set_params(s["params"])
     lf, lc, dbg = blk.train_backward(s["ro"], s["rd"], s["b"], s["rd"], s["label"], debug=True)
     assert dbg["z_fine"].shape == (s["n"], 320)
