@@ -2,8 +2,8 @@
 
 Scene: a TEACHER NeRF (full 8x256 coarse+fine network, random N(0, 2/fan_in) weights scaled up so that the volume is
 not empty) rendered in fp32 by this library from `nviews` poses on the radius-4 sphere = a view-consistent synthetic
-scene of BASELINE's shape without any dataset.  Two STUDENTS (same initial weights, different from the teacher) are
-trained for `steps` Adam steps of 4096 rays drawn from the training views, one with dtype f32 and one with bf16;
+scene of BASELINE's shape without any dataset.  STUDENTS (same initial weights, different from the teacher) are
+trained for `steps` Adam steps of 4096 rays drawn from the training views with dtype f32, f16x3 and bf16, each twice;
 PSNR is measured on a held-out view.  usage: python scripts/psnr_full.py [steps] [hw]"""
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,11 +51,13 @@ init = H.make_params(c, 5, bias_scale=0.0)
 g = torch.Generator(device="cpu").manual_seed(7)
 batches = [torch.randint(0, tr_o.shape[0], (B,), generator=g).cuda() for _ in range(steps)]
 res = {}
-for run in ("f32", "f32#2", "bf16", "bf16#2"):   # every dtype twice: the run-to-run spread (fp32 atomics order) is the noise floor
+for run in ("f32", "f32#2", "f16x3", "f16x3#2", "bf16", "bf16#2"):   # every dtype twice: the run-to-run spread (fp32 atomics order) is the noise floor
     dtype = run.split("#")[0]
     st = NerfBlock(NerfConfig.from_dict(dict(c, maxRays=B, dtype=dtype, lrate=5e-4)))
     st.set_params(init)
+    st.set_stream(torch.cuda.current_stream().cuda_stream)     # the batch gathers below run on torch's stream
     ev = NerfBlock(NerfConfig.from_dict(dict(c, maxRays=n, dtype=dtype)))
+    ev.set_stream(torch.cuda.current_stream().cuda_stream)
     t0 = time.perf_counter()
     curve = []
     for s, idx in enumerate(batches):
@@ -73,5 +75,5 @@ for run in ("f32", "f32#2", "bf16", "bf16#2"):   # every dtype twice: the run-to
     res[run] = curve
     print(run, "train %.1f s" % (time.perf_counter() - t0), " ".join("step %d: %.2f dB" % x for x in curve))
     st.close(); ev.close()
-print("held-out PSNR after %d steps: f32 %.2f / %.2f dB, bf16 %.2f / %.2f dB" %
-      (steps, res["f32"][-1][1], res["f32#2"][-1][1], res["bf16"][-1][1], res["bf16#2"][-1][1]))
+print("held-out PSNR after %d steps: f32 %.2f / %.2f dB, f16x3 %.2f / %.2f dB, bf16 %.2f / %.2f dB" %
+      (steps, res["f32"][-1][1], res["f32#2"][-1][1], res["f16x3"][-1][1], res["f16x3#2"][-1][1], res["bf16"][-1][1], res["bf16#2"][-1][1]))
