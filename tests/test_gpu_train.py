@@ -336,3 +336,48 @@ def test_checkpoint_resume(G, dtype, tmp_path):
     assert np.abs(w.get_params() - a.get_params()).max() > 1e-4
     for blk in (a, b, w):
         blk.close()
+
+
+OTHER_SHAPES = {
+    "w128_dir": dict(D=5, W=128, skips=[2], posL=6, dirL=3, NSamples=20, NImportance=30),
+    "w128_nodir_odd": dict(D=3, W=128, skips=[1], posL=5, dirL=2, NSamples=17, NImportance=9, useDir=False, whiteBkgd=False),
+    "w256_shallow_sh": dict(D=2, W=256, skips=[0], posL=4, dirL=2, NSamples=24, NImportance=40, useSH=True),
+    "d1_flat": dict(D=1, W=64, skips=[], posL=3, dirL=2, NSamples=33, NImportance=0, useHierarchical=False),
+    "w64_deep_sh": dict(D=6, W=64, skips=[1, 3], posL=4, dirL=1, NSamples=16, NImportance=16, useSH=True),
+}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+@pytest.mark.parametrize("variant", sorted(OTHER_SHAPES))
+def test_gradients_other_network_shapes(G, variant, dtype):
+    """Network shapes the golden cases do not reach (W = 128 -> 4 tiles per layer and other wave arrangements in the
+    weight-gradient kernels, odd layer counts, D = 1, a skip right before the head, two skips, sample counts that are no
+    multiple of the 32-sample tile, no hierarchical pass), fp32 and split-f16 training kernels against the oracle:
+    render 2e-4 abs, losses 1e-4, whole gradient < 1e-3 relative L2, every tensor within 5e-3 of its own norm (or of
+    2 % of the largest tensor's, for the tiny ones)."""
+    c = H.cfg(**OTHER_SHAPES[variant])
+    n = 53
+    ro, rd, b, label = H.make_rays(n, 12)
+    params = H.make_params(c, 7)
+    blk = G.make_block(c, dtype=dtype)
+    blk.set_params(params)
+    o = Oracle(c)
+    fine = blk.evaluate(ro, rd, b, rd)
+    np.testing.assert_allclose(fine, o.forward(params, ro, rd, b, rd, training=False)["rgb_fine"], rtol=0, atol=2e-4)
+    lf, lc = blk.train_backward(ro, rd, b, rd, label)
+    gr = blk.get_grads()
+    ref = o.train_grads(params, ro, rd, b, rd, label)
+    rg = ref["grads"]
+    assert lf == pytest.approx(ref["loss_fine"], rel=1e-4)
+    if c["useHierarchical"]:
+        assert lc == pytest.approx(ref["loss_coarse"], rel=1e-4)
+    assert np.isfinite(gr).all()
+    assert np.linalg.norm(gr - rg) / np.linalg.norm(rg) < 1e-3
+    off, spans = 0, []
+    for _ in range(2 if c["useHierarchical"] else 1):
+        for nm, r_, c_ in H.layout(c):
+            spans.append((nm, off, r_ * c_)); off += r_ * c_
+    big = max(np.linalg.norm(rg[o_:o_ + k]) for _, o_, k in spans)
+    for nm, o_, k in spans:
+        assert np.linalg.norm(gr[o_:o_ + k] - rg[o_:o_ + k]) <= 5e-3 * max(np.linalg.norm(rg[o_:o_ + k]), 0.02 * big), nm
+    blk.close()
