@@ -205,14 +205,24 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBfItem& it, char* sme
   }
 }
 
+#ifdef WGB_STAMPS   // diagnostic build only (scripts/x3w_stamps.py <lib> bf16): cycles of every work entry, span of every workgroup
+__device__ unsigned long long g_wgb_entry[8192 * 2];
+__device__ unsigned long long g_wgb_span[1024 * 2];
+#endif
 __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradBfItem* __restrict__ items,
                                                             const int32_t* __restrict__ first) {
   extern __shared__ __attribute__((aligned(1024))) char smem_b[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int e0 = first[blockIdx.x], e1 = first[blockIdx.x + 1];
+#ifdef WGB_STAMPS
+  if (threadIdx.x == 0) g_wgb_span[2 * blockIdx.x] = wall_clock64();
+#endif
   for (int e = e0; e < e1; ++e) {
     const WgradBfItem it = items[e];
     if (it.c0 >= it.c1) continue;
+#ifdef WGB_STAMPS
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int pieces = 2 * (((it.a_rows + 31) >> 5) + ((it.b_rows + 31) >> 5));
     switch (it.shape | (pieces > 16 ? 0x100 : 0)) {
       case 0x144: wgrad_bf16_body<4, 4, 8>(it, smem_b, wave, lane); break;
@@ -234,8 +244,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradBfItem* _
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // every wave is done with the LDS stages before the next entry requests into them
+#ifdef WGB_STAMPS
+    if (threadIdx.x == 0) {
+      g_wgb_entry[2 * e] = __builtin_amdgcn_s_memtime() - t0;
+      g_wgb_entry[2 * e + 1] = ((unsigned long long)it.a_rows << 48) | ((unsigned long long)it.b_rows << 32) | (unsigned long long)(it.c1 - it.c0) << 12 | blockIdx.x;
+    }
+#endif
   }
+#ifdef WGB_STAMPS
+  if (threadIdx.x == 0) g_wgb_span[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
+#ifdef WGB_STAMPS
+extern "C" int nerfhip_debug_wgb_stamps(unsigned long long* entry, unsigned long long* span) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(entry, HIP_SYMBOL(g_wgb_entry), sizeof(unsigned long long) * 8192 * 2) != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(span, HIP_SYMBOL(g_wgb_span), sizeof(unsigned long long) * 1024 * 2) != hipSuccess;
+}
+#endif
 
 // positionCode(viewdir, dirL) of every sample's ray in operand layout (KT = 1): B operand of the Wd gradient
 __global__ __launch_bounds__(256) void expand_encdir_bf16_kernel(const float* __restrict__ viewdir, int64_t M, int S, int Ed,

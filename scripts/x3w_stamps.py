@@ -22,7 +22,8 @@ for _ in range(4):
 tr.synchronize()
 lib = C.CDLL(_lib.LIB_PATH)
 ent = np.zeros(8192 * 2, np.uint64); span = np.zeros(1024 * 2, np.uint64)
-fn = lib.nerfhip_debug_x3w_stamps if dtype == "f16x3" else lib.nerfhip_debug_wgf_stamps
+fn = {"f16x3": "nerfhip_debug_x3w_stamps", "f32": "nerfhip_debug_wgf_stamps", "bf16": "nerfhip_debug_wgb_stamps"}[dtype]
+fn = getattr(lib, fn)
 assert fn(ent.ctypes.data_as(C.c_void_p), span.ctypes.data_as(C.c_void_p)) == 0
 ent = ent.reshape(-1, 2); span = span.reshape(-1, 2)[:256].astype(np.int64)
 kinds = collections.defaultdict(list)
@@ -46,14 +47,15 @@ end = (span[:, 1] - t0) / 100.0
 print(f"workgroup busy time us: min {dur.min():.0f} mean {dur.mean():.0f} max {dur.max():.0f}; last start {(span[:, 0].max() - t0) / 100.0:.0f}; "
       f"finish: min {end.min():.0f} mean {end.mean():.0f} max {end.max():.0f}")
 # spread inside the largest kind, by workgroup and by XCD (workgroup id mod 8)
+big = max(kinds, key=lambda k: sum(x[0] for x in kinds[k]))
 rows = []
 for cyc, info in ent:
     info = int(info)
     if info == 0: continue
     ar, br, nch, wg = info >> 48, (info >> 32) & 0xffff, (info >> 12) & 0xfffff, info & 0xfff
-    if ar == 256 and br == 256 and nch > 200: rows.append((wg, nch, int(cyc) / nch))
+    if ar == big[0] and br == big[1] and nch > 100: rows.append((wg, nch, int(cyc) / nch))
 rows = np.array(rows)
-print("256x256 cycles/chunk: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f" % (rows[:, 2].min(), np.percentile(rows[:, 2], 10), np.median(rows[:, 2]), np.percentile(rows[:, 2], 90), rows[:, 2].max()))
+print(f"{big[0]}x{big[1]} cycles/chunk: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f" % (rows[:, 2].min(), np.percentile(rows[:, 2], 10), np.median(rows[:, 2]), np.percentile(rows[:, 2], 90), rows[:, 2].max()))
 for x in range(8):
     sel = rows[rows[:, 0].astype(int) % 8 == x]
     print(f"  xcd {x}: {len(sel):3d} entries, mean cycles/chunk {sel[:, 2].mean():.0f}; busy us of its workgroups: mean {dur[x::8].mean():.0f} max {dur[x::8].max():.0f}")
