@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "launchers.h"
-#include "rng.cuh"
+#include "rng.hip.h"
 
 using namespace nh;
 
@@ -42,7 +42,7 @@ struct Net {
   float* d_wpack_fwd = nullptr;
   float* d_wpack_bwd = nullptr;
   float* d_vecpack = nullptr;
-  // bf16 path (cfg.dtype == NERFHIP_BF16): fragment streams (bf16_common.cuh) and fp32 vectors
+  // bf16 path (cfg.dtype == NERFHIP_BF16): fragment streams (bf16_common.hip.h) and fp32 vectors
   std::vector<FragDesc> bf_full, bf_sigma;      // forward stream with the colour head / with the density tile only
   FragDesc* d_bf_full_desc = nullptr;
   FragDesc* d_bf_sigma_desc = nullptr;
@@ -52,7 +52,7 @@ struct Net {
   std::vector<FragDesc> bf_bwd;                 // backward stream (transposed matrices)
   FragDesc* d_bf_bwd_desc = nullptr;
   void* d_bf_bwd = nullptr;
-  // split-f16 path (cfg.dtype == NERFHIP_F16X3): forward streams of (hi, lo) fragment pairs (f16x3_common.cuh)
+  // split-f16 path (cfg.dtype == NERFHIP_F16X3): forward streams of (hi, lo) fragment pairs (f16x3_common.hip.h)
   std::vector<FragDesc> x3_full, x3_sigma, x3_bwd;   // x3_bwd: transposed matrices, for the backward kernel
   FragDesc* d_x3_full_desc = nullptr;
   FragDesc* d_x3_sigma_desc = nullptr;

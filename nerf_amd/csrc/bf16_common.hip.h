@@ -1,6 +1,6 @@
-// bf16_common.cuh -- machinery of the bf16-MFMA MLP kernels (gfx950, v_mfma_f32_32x32x16_bf16).
+// bf16_common.hip.h -- machinery of the bf16-MFMA MLP kernels (gfx950, v_mfma_f32_32x32x16_bf16).
 //
-// Same transposed formulation as the fp32 kernels (mlp_common.cuh): activations H^T [features][samples] with
+// Same transposed formulation as the fp32 kernels (mlp_common.hip.h): activations H^T [features][samples] with
 // the sample on the lane, weights as the A operand, fp32 accumulators.  What changes with bf16:
 //   * one MFMA contracts 16 features (lane half h holds 8 consecutive-in-register bf16) and takes 8 passes, i.e.
 //     16x the fp32 rate: the A fragments (1 KiB per wave per MFMA) can no longer come from L2 -- they are staged
@@ -19,7 +19,7 @@
 // before the end of the block so the fragment prefetch (3 ahead, asm ds_read_b128 with counted lgkmcnt) runs
 // across block boundaries without a bubble.  The allocation is padded so requests past the end stay in bounds.
 #pragma once
-#include "mlp_common.cuh"
+#include "mlp_common.hip.h"
 
 namespace nh {
 

@@ -40,7 +40,7 @@ struct ChunkDesc {
   uint32_t pad;
 };
 
-// One 1-KiB fragment of a packed bf16 weight stream (bf16_common.cuh): 32 rows x 16 k-values of one matrix.
+// One 1-KiB fragment of a packed bf16 weight stream (bf16_common.hip.h): 32 rows x 16 k-values of one matrix.
 struct FragDesc {
   int64_t src_off;     // float offset of the matrix in the canonical network parameters; < 0: all-zero fragment
   int32_t ld;          // row length of the canonical matrix
@@ -88,7 +88,7 @@ struct ActStore {
 };
 // bf16 training store (cfg.dtype == NERFHIP_BF16).  Every buffer is in MFMA-operand layout: per 32-sample tile
 // and per 32-feature k-tile kt two 1-KiB fragments (k-step s = 0, 1) of [lane = 32h + sample][8 bf16], element e
-// of lane half h holding feature 32kt + bf_feature(s,h,e) (bf16_common.cuh) -- exactly the registers the fused
+// of lane half h holding feature 32kt + bf_feature(s,h,e) (bf16_common.hip.h) -- exactly the registers the fused
 // kernels hold, so a wave stores/loads a fragment with ONE 16-byte access per lane, and the bf16 weight-gradient
 // kernel turns it into sample-contiguous MFMA operands with ds_read_b64_tr_b16 (wgrad_bf16.hip).
 //   fragment (tile, kt, s) of a buffer with KT k-tiles: byte offset ((tile*KT + kt)*2 + s) * 1024
@@ -99,7 +99,7 @@ struct BfStore {
   uint16_t* dy;      // [D] x (KT = W/32) gradients w.r.t. the trunk pre-activations
   uint16_t* dh;      // KT = HT + 1       head gradients; tile HT: feature 0 = d sigma, 1..3 = d craw
   uint16_t* encdir;  // KT = 1            mode 1: positionCode(viewdir) of the sample's ray
-  uint32_t* relu;    // [D] x 16 B per lane of every 32-sample tile: ReLU' bits of the trunk layers (bf16_common.cuh:
+  uint32_t* relu;    // [D] x 16 B per lane of every 32-sample tile: ReLU' bits of the trunk layers (bf16_common.hip.h:
                      // relu_bits), layer l at relu + l*Mpad*8 words
   int64_t Mpad;
 };

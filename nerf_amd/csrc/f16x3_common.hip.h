@@ -1,4 +1,4 @@
-// f16x3_common.cuh -- machinery of the SPLIT-f16 MLP forward kernel (gfx950, v_mfma_f32_32x32x16_f16): fp32-grade
+// f16x3_common.hip.h -- machinery of the SPLIT-f16 MLP forward kernel (gfx950, v_mfma_f32_32x32x16_f16): fp32-grade
 // results at matrix-core rates.
 //
 // Every fp32 operand is split into two f16 halves of 11 significant bits each and a product of two such numbers is
@@ -19,14 +19,14 @@
 // larger alike -- while the three MFMAs run at the f16 rate: 2.5 PF / 3 = 833 TF of fp32-grade contraction against
 // the 157 TF of v_mfma_f32_32x32x2_f32.  Range: |x| < 65504 and |w| < 1023.
 //
-// Structure: that of the bf16 kernels (bf16_common.cuh) -- transposed formulation, output-tile-outer loop, weight
+// Structure: that of the bf16 kernels (bf16_common.hip.h) -- transposed formulation, output-tile-outer loop, weight
 // fragments through a 4 x 32 KiB LDS ring fed by LDS-DMA, asm ds_read_b128 with counted lgkmcnt, the epilogue of
 // tile t cut into pieces that issue between the MFMAs of tile t+1 -- with these differences: the stream carries a
 // (hi, lo) PAIR of 1-KiB fragments per (output tile, k-step); a step is one pair and three MFMAs; activations are
 // kept as (hi, lo) operand pairs, which needs the 512-register file: ONE wave per SIMD, 4 waves (128 samples) per
 // workgroup.
 #pragma once
-#include "mlp_common.cuh"
+#include "mlp_common.hip.h"
 #ifndef NH_X3_PD
 #define NH_X3_PD 2
 #endif
@@ -69,7 +69,7 @@ struct Ring {
   int nblk, blk, req, req_src, wave, lane;
   // training kernel: VMEM operations of this wave behind the pieces of block blk+1 (young_a: up to the request of
   // block blk+2, young_b: since) -- activation / mask stores, counted by note(); vmcnt retires in order, so counting
-  // them lets the stores stay in flight across sync points (as bf16_common.cuh: BfRing)
+  // them lets the stores stay in flight across sync points (as bf16_common.hip.h: BfRing)
   int young_a, young_b;
   __device__ __forceinline__ void note(int n) { young_b += n; }
   uint32_t voff;        // this lane's byte offset inside a block: wave quarter + lane * 16

@@ -2,15 +2,15 @@
 //
 // Reverse mode of nerfCoreBlock.forwardInternal (reference nerf/nerfCoreBlock.scala:17-112; the reference
 // gets it from libtorch autograd via DJL's GradientCollector, runNerf.scala:96-105).  Same transposed
-// formulation as the forward kernel (mlp_common.cuh): the gradient w.r.t. a layer's pre-activations,
+// formulation as the forward kernel (mlp_common.hip.h): the gradient w.r.t. a layer's pre-activations,
 // dY_l^T (W x 32 samples per wave), lives in accumulator registers and is directly the B operand of
 //     dX^T = W_l^T . dY_l^T
 // with W_l^T read straight from the packed backward stream in L2 through the continuous fragment ring of
-// mlp_common.cuh.  The ReLU masks are the sign bitmasks written by the training forward pass; every dY_l^T
+// mlp_common.hip.h.  The ReLU masks are the sign bitmasks written by the training forward pass; every dY_l^T
 // (and the head gradients) is stored feature-major for the weight-gradient GEMM (wgrad.hip), two rows per
 // tile step between the fragment loads.  Positions carry no gradient, so layer 0 and
 // the encoding half of a skip input produce no dX.
-#include "mlp_common.cuh"
+#include "mlp_common.hip.h"
 
 namespace nh {
 
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_f32_kernel(NetArgs net, const 
   }
   if constexpr (kFast) {
     // The fragment ring is primed directly in front of its first part (asm loads are only in flight inside a
-    // part, mlp_common.cuh) and then runs through the whole stream.  The head chunks are walked even without a
+    // part, mlp_common.hip.h) and then runs through the whole stream.  The head chunks are walked even without a
     // colour gradient (dh = 0 then), which keeps the control flow free of un-primed paths.
     prime_frags(fr, wp, fvoff);
     mm_layer_g<WT, R, 1, true>(acc, &dh[0], fr, wp, fvoff, StoreSide<1, WT>{&dh[0], dhb, voff});

@@ -2,7 +2,7 @@
 //
 // Reverse mode of nerfCoreBlock.forwardInternal (reference nerf/nerfCoreBlock.scala:17-112; the reference gets it
 // from libtorch autograd, runNerf.scala:96-105) with bf16 MFMA operands and fp32 accumulation, same machinery as
-// the bf16 forward (bf16_common.cuh): the gradient tile in the accumulators becomes -- masked by ReLU', rounded
+// the bf16 forward (bf16_common.hip.h): the gradient tile in the accumulators becomes -- masked by ReLU', rounded
 // to bf16 -- the B operand of  dX^T = W_l^T . dY_l^T  and is stored (operand layout, common.h: BfStore) for the
 // bf16 weight-gradient kernel.  ReLU' comes from the stored bf16 activations (a value is > 0 iff its bf16 is
 // non-zero), applied to packed pairs: mask = 0 - min(act, 1) per 16-bit half, three VALU per two values.
@@ -10,7 +10,7 @@
 //   (mode 1) colour output layer Wc^T: HT tiles x 1 k-step | head: WT tiles x (2 HT k-steps of Wf^T + 1 k-step
 //   whose k = 0 is the density row) | layers D-1 .. 1: WT tiles x 2 WT k-steps of W_l^T (first W input columns).
 #include <algorithm>
-#include "bf16_common.cuh"
+#include "bf16_common.hip.h"
 #include "launchers.h"
 
 namespace nh {

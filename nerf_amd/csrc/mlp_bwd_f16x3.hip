@@ -3,7 +3,7 @@
 // reference gets it from libtorch autograd, runNerf.scala:96-105) to fp32 accuracy at matrix-core rates, for training
 // steps with dtype f16x3.  It reads what the training forward wrote into the fp32 activation store (ReLU sign bits) and
 // writes what mlp_bwd.hip writes (every dY_l^T and the head gradients, fp32, tile-major) for the fp32 weight-gradient
-// kernel; machinery and arithmetic of the forward (f16x3_common.cuh: weights 64 w = hi + lo, three MFMAs per k-step
+// kernel; machinery and arithmetic of the forward (f16x3_common.hip.h: weights 64 w = hi + lo, three MFMAs per k-step
 // into one accumulator).
 //
 // Gradients need one thing activations do not: a SCALE.  d(loss)/d(pre-activation) of a sample is 1e-4 .. 1e-12, far
@@ -19,7 +19,7 @@
 //
 // Backward stream (api.hip: build_bwd_stream, pairs): (mode 1) Wc^T, HT tiles x 1 k-step | head: WT tiles x (2 HT
 // k-steps of Wf^T + 1 k-step whose k = 0 is the density row) | layers D-1 .. 1: WT tiles x 2 WT k-steps of W_l^T.
-#include "f16x3_common.cuh"
+#include "f16x3_common.hip.h"
 #include <algorithm>
 #include "launchers.h"
 
@@ -98,9 +98,9 @@ template <int NT>
 struct EpiGrad {
   GradRegs<NT>& out;
   Ring& rg;
-  float* dst;            // wave-uniform: this wave's tile block of the gradient buffer (mlp_common.cuh: tile_block)
+  float* dst;            // wave-uniform: this wave's tile block of the gradient buffer (mlp_common.hip.h: tile_block)
   uint32_t voff;         // tile_voff(lane)
-  const uint32_t (&bits)[4];   // the layer's sign-bit words of this lane (mlp_common.cuh: relu_mask_words)
+  const uint32_t (&bits)[4];   // the layer's sign-bit words of this lane (mlp_common.hip.h: relu_mask_words)
   float kx;              // 2^(e_out - e_in - 6): accumulator -> next operand
   float kst;             // 2^(-e_in - 6):        accumulator -> true gradient
   float amax;            // running max |masked accumulator| of this lane

@@ -1,4 +1,4 @@
-// mlp_common.cuh -- device helpers shared by the fused MLP kernels (fp32 MFMA path).
+// mlp_common.hip.h -- device helpers shared by the fused MLP kernels (fp32 MFMA path).
 //
 // Formulation (all MLP kernels): activations are kept TRANSPOSED, H^T [features][samples], with the
 // sample on the MFMA lane and the features in the accumulator registers:

@@ -10,9 +10,9 @@
 // Work decomposition: one workgroup = 4 waves = 128 samples; one wave = 32 samples x all features;
 // 1 wave per SIMD with the 512-register file (accumulators 128 + previous layer 128 + encoding 32).
 // Weights: every wave reads its 32x32 fragments straight from the packed stream in L2 through a ring of
-// prefetched register sets that runs continuously across layers (mlp_common.cuh, "direct-from-L2"); the
+// prefetched register sets that runs continuously across layers (mlp_common.hip.h, "direct-from-L2"); the
 // training variant interleaves the activation stores with those loads.
-#include "mlp_common.cuh"
+#include "mlp_common.hip.h"
 
 namespace nh {
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
   // Rows past M repeat sample M-1 (finite values); their gradients are zero in the backward pass, so the
   // stored activations of those columns never contribute to a weight gradient.
   f32x16 enc[2];
-  if (trig_reduced(px, py, pz, net.E)) {   // wave-uniform: the usual case, sin/cos by the short routine (mlp_common.cuh)
+  if (trig_reduced(px, py, pz, net.E)) {   // wave-uniform: the usual case, sin/cos by the short routine (mlp_common.hip.h)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_f32_kernel(NetArgs net, const 
       for (int r = 0; r < 16; ++r) act[t][r] = fmaxf(acc[t][r], 0.f);
   };
   // layer 0: encoding only.  The fragment ring is primed directly in front of its first part: asm loads are
-  // only ever in flight inside a part (mlp_common.cuh).
+  // only ever in flight inside a part (mlp_common.hip.h).
   load_rows<WT>(acc, sbias, WT, W, h);  // accumulator := bias
   if constexpr (kFast) {
     prime_frags(fr, wp, fvoff);

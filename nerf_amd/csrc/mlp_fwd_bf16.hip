@@ -3,13 +3,13 @@
 // Same function as mlp_fwd.hip (reference nerf/nerfCoreBlock.scala:17-112) with bf16 MFMA operands and fp32
 // accumulation (BASELINE config 5; parity bar: renders within 1e-2 abs of the fp32 path).  Positions, the
 // encoding's sin/cos, biases, the per-ray view-direction branch and all accumulators are fp32; weights and
-// the activations fed to the next layer are rounded to bf16 (RNE).  Machinery: bf16_common.cuh.
+// the activations fed to the next layer are rounded to bf16 (RNE).  Machinery: bf16_common.hip.h.
 // One wave = 32 samples x all features; workgroup = 8 waves = 256 samples, persistent (one per CU).
 // Stream layout (api.hip: build_bf16_stream): layer 0 | layers 1..D-1 (skip layers carry 4 extra k-steps for
 // the encoding) | head: HT colour-hidden tiles + one tile whose row 0 is the density row | (mode 1) colour
 // output layer, 1 tile over K = 32 HT.  The sigma-only stream (coarse pass of inference) ends with the density
 // tile alone.
-#include "bf16_common.cuh"
+#include "bf16_common.hip.h"
 #include <algorithm>
 #include "launchers.h"
 

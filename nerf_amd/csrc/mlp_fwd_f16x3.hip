@@ -1,9 +1,9 @@
 // mlp_fwd_f16x3.hip -- fused positional-encoding + density/colour MLP forward with SPLIT-f16 MFMA operands (gfx950),
 // inference: the function of mlp_fwd.hip (reference nerf/nerfCoreBlock.scala:17-112) to fp32 accuracy at matrix-core
-// rates (f16x3_common.cuh: x = hi + lo, three v_mfma_f32_32x32x16_f16 per product into one fp32 accumulator that
+// rates (f16x3_common.hip.h: x = hi + lo, three v_mfma_f32_32x32x16_f16 per product into one fp32 accumulator that
 // carries the factor 64 of the packed weights).
 // Held to the SAME parity bars as the fp32 kernels (tests: every fp32 render test also runs with dtype f16x3).
-// Positions, the encoding's sin/cos (accurate ones, mlp_common.cuh, not the hardware approximations of the bf16 path), biases,
+// Positions, the encoding's sin/cos (accurate ones, mlp_common.hip.h, not the hardware approximations of the bf16 path), biases,
 // the per-ray view-direction branch and all accumulators are fp32.
 // TRAIN variant (forward of a training step with dtype f16x3; backward and weight gradient stay on the fp32 kernels):
 // the same arithmetic, and every post-ReLU activation, the encoding, the colour hidden layer and the ReLU sign bits are
@@ -18,7 +18,7 @@
 #ifndef NERFHIP_DIAG_STAMPS
 #define NERFHIP_DIAG_STAMPS 0
 #endif
-#include "f16x3_common.cuh"
+#include "f16x3_common.hip.h"
 #include <algorithm>
 #include "launchers.h"
 
@@ -47,7 +47,7 @@ struct SelHid {
   template <int KS_IDX> __device__ __forceinline__ const Pair& b() const { return a.v[KS_IDX / 2][KS_IDX % 2]; }
 };
 
-// In every epilogue `a` is the finished accumulator tile = 64 x (W x + b) (f16x3_common.cuh: kWScale).
+// In every epilogue `a` is the finished accumulator tile = 64 x (W x + b) (f16x3_common.hip.h: kWScale).
 
 // relu on the integer bits (negative floats and -0 are negative integers): one v_max_i32 where fmaxf on a value that
 // comes out of an asm-free register costs a canonicalising v_max_f32 as well
@@ -55,7 +55,7 @@ __device__ __forceinline__ float relu_bits(float x) { return __builtin_bit_cast(
 
 // what the TRAIN epilogues need to write a tile into the activation store
 struct StoreCtx {
-  float* dst;          // wave-uniform: this wave's 32-sample tile block of the layer's buffer (mlp_common.cuh: tile_block)
+  float* dst;          // wave-uniform: this wave's 32-sample tile block of the layer's buffer (mlp_common.hip.h: tile_block)
   uint32_t voff;       // tile_voff(lane)
   uint32_t* mask;      // this lane's word 0 of the layer's sign-bit slot (mask_ptr(.., w = 0, ..)); word w at + w * Mpad
   int64_t Mpad;
@@ -66,7 +66,7 @@ __device__ __forceinline__ float* uniform_ptr(float* p) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
   return (float*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
-// sign bit of a post-ReLU value, at bit position POS of a mask word ("> 0" on the integer bits, mlp_common.cuh)
+// sign bit of a post-ReLU value, at bit position POS of a mask word ("> 0" on the integer bits, mlp_common.hip.h)
 template <int POS>
 __device__ __forceinline__ uint32_t sign_bit_at(float v) { return (uint32_t)min(__builtin_bit_cast(int, v), 1) << POS; }
 

@@ -1,11 +1,11 @@
 // pack.hip -- re-lays the canonical fp32 parameters (DJL order, W[out][in]) into the streams the fused MLP
 // kernels consume, the per-ray view-direction branch of the colour head, Adam and the L2 loss.
-//   * weight chunks: 32 k-values x R rows, image [g = k/4][i][k%4] (see mlp_common.cuh); the forward
+//   * weight chunks: 32 k-values x R rows, image [g = k/4][i][k%4] (see mlp_common.hip.h); the forward
 //     stream holds W_l, the backward stream W_l^T (so both are the A operand of the same MFMA loop);
 //   * vecpack: 16-byte aligned copies of biases / density row / colour output rows.
 // Runs once per set_params and once after every optimizer step (about 2x the parameter bytes).
 #include "launchers.h"
-#include "rng.cuh"
+#include "rng.hip.h"
 
 namespace nh {
 
@@ -14,7 +14,7 @@ __global__ void pack_chunks_kernel(const float* __restrict__ params, const Chunk
   const ChunkDesc d = descs[blockIdx.x];
   const float* src = params + d.src_off;
   const int total = 32 * d.R;
-  // tile-linear image (mlp_common.cuh): e = (((ot*4 + q)*64 + h*32 + li)*4 + j)  <->  row i = 32 ot + li,
+  // tile-linear image (mlp_common.hip.h): e = (((ot*4 + q)*64 + h*32 + li)*4 + j)  <->  row i = 32 ot + li,
   // k = 8q + 4h + j: one output tile of the chunk = 4 KiB contiguous = four 1-KiB wave loads
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int j = e & 3, lane = (e >> 2) & 63, q = (e >> 8) & 3, ot = e >> 10;
@@ -36,14 +36,14 @@ __device__ __forceinline__ void pack_frag_bf16(const float* __restrict__ params,
   const int row = d.row0 + i;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int f = 16 * d.s + (e & 3) + 8 * (e >> 2) + 4 * h;   // bf16_common.cuh: bf_feature
+    const int f = 16 * d.s + (e & 3) + 8 * (e >> 2) + 4 * h;   // bf16_common.hip.h: bf_feature
     float v = 0.f;
     if (d.src_off >= 0 && row < d.nrows && f < d.kvalid)
       v = d.transposed ? src[(int64_t)(d.col0 + f) * d.ld + row] : src[(int64_t)row * d.ld + d.col0 + f];
     o[e] = (__bf16)v;
   }
 }
-// split-f16 weight streams (f16x3_common.cuh): descriptor i -> fragment 2i = hi = f16(64 w), fragment 2i+1 = lo =
+// split-f16 weight streams (f16x3_common.hip.h): descriptor i -> fragment 2i = hi = f16(64 w), fragment 2i+1 = lo =
 // f16(64 w - hi); same lane / element order as the bf16 fragments
 __global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __restrict__ params,
                                                               const FragDesc* __restrict__ descs,

@@ -14,7 +14,7 @@
 // hence ANY summation order -- including this parallel scan -- yields bit-identical fp32 CDF entries
 // and therefore bit-identical bin indices.
 #include "common.h"
-#include "rng.cuh"
+#include "rng.hip.h"
 
 namespace nh {
 

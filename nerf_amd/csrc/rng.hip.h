@@ -1,4 +1,4 @@
-// rng.cuh -- counter-based Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
+// rng.hip.h -- counter-based Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
 // Used for givePerturb / givePerturbPDF / addNoise (nerfBlock.scala:21,55,71) and parameter init when
 // the caller does not pass explicit random tensors.  Stateless: value = f(seed, stream, step, index).
 #pragma once

@@ -16,7 +16,7 @@
 // (host: train_impl.inc), so there is no tail and only ~n_cu + #products accumulator flushes per step.
 // The k order inside an 8-sample group is permuted (lane half h takes samples 4h..4h+3) identically for A
 // and B, so one 16-byte LDS read feeds four MFMAs.
-#include "mlp_common.cuh"
+#include "mlp_common.hip.h"
 #include <type_traits>
 #include "launchers.h"
 

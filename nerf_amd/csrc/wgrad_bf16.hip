@@ -13,7 +13,7 @@
 // chunk of a 256x256 product = 32 KiB of operands for 32 MFMAs per wave), so the staging ring is 4 deep with
 // counted vmcnt waits, and the staged image is swizzled (wb_slot) so the transposed reads are bank-conflict free.
 // Bias gradients (row sums of A) are v_dot2_f32_bf16 sums over the A fragments a wave holds anyway.
-#include "bf16_common.cuh"
+#include "bf16_common.hip.h"
 #include "launchers.h"
 
 namespace nh {

@@ -2,7 +2,7 @@
 //   dW[i][j] = sum_m  A[i][m] * B[j][m]          A = dY^T (gradient rows), B = X^T (input feature rows)
 // on the SAME fp32 operands in the SAME tile-major store, staged into the same swizzled LDS image by the same
 // persistent work list -- but contracted on the f16 matrix pipe: every fragment a wave reads from LDS (four fp32
-// samples of a row) is split in registers into two f16 halves (f16x3_common.cuh: v = hi + lo) and a 16-sample k-step
+// samples of a row) is split in registers into two f16 halves (f16x3_common.hip.h: v = hi + lo) and a 16-sample k-step
 // takes three v_mfma_f32_32x32x16_f16 (hi.hi + hi.lo + lo.hi) into the fp32 accumulators, 5.3 x fewer matrix-pipe
 // cycles than v_mfma_f32_32x32x2_f32 spends on the product.  The kernel is then bound by its 20 GB operand stream.
 // Scale: the gradient rows are 1e-4 .. 1e-12, so A is multiplied by a power of two G chosen from the largest |dY| of
@@ -10,7 +10,7 @@
 // an element 2^-14 below the largest one keeps 22 bits, smaller ones are exact to 2^-37 of the largest -- a sum over
 // a million samples dominated by the large terms does not see it.  The accumulators are multiplied by 1/G on their
 // way out (exact).  Bias gradients stay fp32 row sums of the A fragments.
-#include "f16x3_common.cuh"
+#include "f16x3_common.hip.h"
 #include <type_traits>
 #include "launchers.h"
 
@@ -80,7 +80,7 @@ __device__ __forceinline__ void split4_by_lo(Pair& p, const f32x4& v, float k) {
   asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v[3]), "s"(k), "v"(h1));
   p.lo[2 * HALF] = l0; p.lo[2 * HALF + 1] = l1;
 }
-// the same unscaled (f16x3_common.cuh: split_into)
+// the same unscaled (f16x3_common.hip.h: split_into)
 template <int HALF>
 __device__ __forceinline__ void split4_hi(Pair& p, const f32x4& v) {
   const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};

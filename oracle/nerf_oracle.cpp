@@ -593,7 +593,7 @@ void orc_mlp_forward(const orc_config* c, const float* net_params, int32_t is_co
 }
 
 // The same network evaluated in the SUMMATION ORDER of the fp32 MFMA kernels (nerf_amd/csrc/mlp_fwd.hip,
-// mlp_common.cuh:9-17), so that a test can hold the kernel to (near-)bitwise agreement instead of the loose bar a
+// mlp_common.hip.h:9-17), so that a test can hold the kernel to (near-)bitwise agreement instead of the loose bar a
 // different GEMM order forces: every Linear output is  acc = bias;  for kt, q, j, h: k = 32 kt + 8 q + 4 h + j:
 // acc = fmaf(w[k], x[k], acc)  (v_mfma_f32_32x32x2_f32 == an fmaf chain over its two k values, bitwise); the density
 // row and the colour output rows are two chains, one per lane half h (k = 32 t + 8 q + 4 h + j), added at the end;

@@ -96,7 +96,7 @@ void orc_sample_pdf(const orc_config* c, int64_t B, const float* w, const float*
 void orc_mlp_forward(const orc_config* c, const float* net_params, int32_t is_coarse, int32_t training,
                      int64_t B, int32_t S, const float* rays_o, const float* rays_d, const float* viewdir,
                      const float* z, float* sigma, float* craw);
-/* The same network with every dot product summed in the order the fp32 MFMA kernels use (nerf_amd/csrc/mlp_common.cuh:
+/* The same network with every dot product summed in the order the fp32 MFMA kernels use (nerf_amd/csrc/mlp_common.hip.h:
  * k = 32kt + 8q + 4h + j, fmaf chain): restates the KERNEL's rounding, not the reference's, so that tests can demand
  * bit-for-bit agreement of the MLP stage where no sin/cos is involved (posL = dirL = 0) and ~1e-6 elsewhere. */
 void orc_mlp_forward_korder(const orc_config* c, const float* net_params, int32_t want_rgb, int64_t B, int32_t S,

@@ -2,7 +2,7 @@
 """Static safety check of the fused MLP kernels' ISA (gfx950).
 
 The kernels issue their weight-fragment loads as inline asm and wait for them with hand-counted
-`s_waitcnt vmcnt(N)` many instructions later (nerf_amd/csrc/mlp_common.cuh); wgrad.hip does the same with LDS
+`s_waitcnt vmcnt(N)` many instructions later (nerf_amd/csrc/mlp_common.hip.h); wgrad.hip does the same with LDS
 reads and lgkmcnt.  The compiler does not know
 that the destination VGPRs of such a load are "in flight": if its register allocator copies, spills or
 re-uses one of them before the load has landed, the kernel computes garbage or -- when the register is

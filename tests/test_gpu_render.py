@@ -255,7 +255,7 @@ def test_mlp_forward_ragged_tile(G, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_mlp_forward_far_positions(G, dtype):
-    """Encoding arguments beyond the short sin/cos routine's range (|p| * 2^(posL-1) > 8192, mlp_common.cuh: kTrigMax):
+    """Encoding arguments beyond the short sin/cos routine's range (|p| * 2^(posL-1) > 8192, mlp_common.hip.h: kTrigMax):
     waves whose samples are all far, and waves that mix far and near samples, take libm's functions; same bar."""
     c = H.CONFIGS["small_dir"]
     o = Oracle(c)
