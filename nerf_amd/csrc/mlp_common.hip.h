@@ -83,31 +83,38 @@ __device__ __forceinline__ void mfma16(f32x16& acc, const f32x4 (&a)[4], const f
 //
 // HAZARD NOTE: "VALU writes SGPR -> VMEM reads that SGPR" needs 5 wait states on gfx9 (CDNA ISA, manually
 // inserted wait states).  hipcc inserts them for its own instructions but does not look inside inline asm, and
-// it does reload spilled SGPR bases with v_readlane right in front of an asm statement -- so every asm
-// statement here that reads an SGPR address starts with s_nop 4 (hidden in the shadow of the running MFMA).
+// it does reload spilled SGPR bases with v_readlane right in front of an asm statement.  So every asm statement
+// here that reads an SGPR address first copies it with s_mov_b64 into a pair of its own: the SALU read of a
+// VALU-written SGPR is interlocked, and so is the VMEM read of the SALU-written copy.  (The first version put
+// s_nop 4 there instead: ~16 cycles more per statement than one SALU instruction -- with 128 stores per layer and
+// wave that was 2.4 % of the fp32 training forward and 5 % of the split-f16 one.)
 template <int T>   // tile T of the part that starts at base: 4 KiB at base + T*4 KiB, fragment q at +q KiB
 __device__ __forceinline__ void gload_tile(f32x4 (&a)[4], const float* base, uint32_t voff) {
+  uint64_t sb;
   asm volatile(
-      "s_nop 4\n\t"
-      "global_load_dwordx4 %0, %4, %5\n\t"
-      "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
-      "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
-      "global_load_dwordx4 %3, %4, %5 offset:3072"
-      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+      "s_mov_b64 %4, %6\n\t"
+      "global_load_dwordx4 %0, %5, %4\n\t"
+      "global_load_dwordx4 %1, %5, %4 offset:1024\n\t"
+      "global_load_dwordx4 %2, %5, %4 offset:2048\n\t"
+      "global_load_dwordx4 %3, %5, %4 offset:3072"
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&s"(sb)
       : "v"(voff), "s"(base + T * 1024));
 }
 __device__ __forceinline__ void gload_frag(f32x4& a, const float* sbase, uint32_t voff) {
-  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(a) : "v"(voff), "s"(sbase));
+  uint64_t sb;
+  asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1" : "=&v"(a), "=&s"(sb) : "v"(voff), "s"(sbase));
 }
 __device__ __forceinline__ void gload4u(uint32_t& d, const uint32_t* sbase, uint32_t voff) {
-  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase));
+  uint64_t sb;
+  asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dword %0, %2, %1" : "=&v"(d), "=&s"(sb) : "v"(voff), "s"(sbase));
 }
 template <int OFF>   // immediate byte offset, < 4096
 __device__ __forceinline__ void gstore4(float* sbase, uint32_t voff, float v) {
   static_assert(OFF >= 0 && OFF < 4096, "global immediate offset");
   // nt: the stored activations / gradients are read once, much later, by another kernel; non-temporal keeps them from
   // pushing the packed weight stream (which every wave re-reads from L2) out of the XCD's L2
-  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(sbase), "n"(OFF));
+  uint64_t sb;
+  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 offset:%4 nt" : "=&s"(sb) : "v"(voff), "v"(v), "s"(sbase), "n"(OFF));
 }
 constexpr int kNB = 4;   // fragment ring: 1 computing + 3 tiles (768 MFMA-cycles) in flight
 
