@@ -119,7 +119,13 @@ struct WgradItem {
   // wgrad_f16x3.hip only: largest |element| of the buffer A lives in (device, written by mlp_bwd_f16x3.hip) and
   // log2 of how many such elements an A value may be the sum of (the per-ray sums of the direction branch)
   const float* amax;
-  int32_t amax_shift, pad_;
+  int32_t amax_shift;
+  // wgrad_f16x3.hip only: an extra VECTOR product that rides on this entry's pass over B -- row x_row of the buffer A
+  // lives in (e.g. d sigma behind the head gradient rows) against every B row: dWx[col0 + j] += sum_m e[m] B[j][m],
+  // dbx += sum_m e[m]; fp32 FMAs on the B fragments the waves hold anyway.  x_row < 0: none
+  int32_t x_row;
+  float* dWx;
+  float* dbx;
 };
 hipError_t prepare_wgrad_f16x3();
 hipError_t launch_wgrad_f16x3(const WgradItem* d_items, const int32_t* d_first, int ngroups, hipStream_t s);

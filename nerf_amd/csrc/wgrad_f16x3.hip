@@ -105,7 +105,8 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // One workgroup = one work entry; wave (wa, wb) owns A tiles [AT*wa, +AT) x B tiles [BT*wb, +BT).
-template <int AT, int BT>
+// XR: the entry carries an extra vector product (WgradItem::x_row)
+template <int AT, int BT, bool XR = false>
 __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int wave, int lane) {
   static_assert((AT == 1 || AT == 2 || AT == 4) && (BT == 1 || BT == 2 || BT == 4), "");
   const int li = lane & 31, h = lane >> 5;
@@ -154,13 +155,14 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
   // chunk j frees A(j)'s slot for B(j+2).  The wait in front of that barrier leaves A(j+2) -- the youngest DMAs of
   // this wave -- in flight (a raw s_barrier: __syncthreads() would put vmcnt(0) in front of it).
   const int64_t a_step = (int64_t)it.a_stride * 32, b_step = (int64_t)it.b_stride * 32;   // floats per chunk
-  const int nA8 = (it.a_rows + 7) >> 3, nB8 = (it.b_rows + 7) >> 3;
+  const int a_stage = XR ? max(it.a_rows, it.x_row + 1) : it.a_rows;   // rows of A's buffer that are staged
+  const int nA8 = (a_stage + 7) >> 3, nB8 = (it.b_rows + 7) >> 3;
   const int nPA = __builtin_amdgcn_readfirstlane(min(max((nA8 - wave + 3) >> 2, 0), 8));   // this wave's pieces of an A chunk
   uint32_t offA[8], offB[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int r = 8 * (wave + 4 * t) + (lane >> 3), sl = (lane & 7) ^ ((r >> 1) & 7);
-    offA[t] = (uint32_t)((min(r, it.a_rows - 1) * 32 + 4 * sl) * 4);   // rows past the end repeat the last row (never stored)
+    offA[t] = (uint32_t)((min(r, a_stage - 1) * 32 + 4 * sl) * 4);   // rows past the end repeat the last row (never stored)
     offB[t] = (uint32_t)((min(r, it.b_rows - 1) * 32 + 4 * sl) * 4);
   }
   // piece T of operand OP (0: A, 1: B) of chunk c into ring slot `slot`
@@ -193,12 +195,24 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
   constexpr int RA0 = NM / 6, RA1 = NM / 2, RB0 = NM / 2 + NM / 6;
   Pair sA[2][AT], sB[2][BT];
   f32x4 fa[AT], fb[BT];
+  // XR: the k-group's four samples of the extra vector (the same for every lane of a half), its products with the B
+  // fragments summed per B row in fp32 (every wave sums, the waves with wa == 0 flush), and its own sum
+  f32x4 fe;
+  float dsum[BT], esum = 0.f;
+#pragma unroll
+  for (int j = 0; j < BT; ++j) dsum[j] = 0.f;
+  const uint32_t laneX = XR ? lds0 + (uint32_t)it.x_row * 128u : 0u;
+  const uint32_t swx = XR ? (uint32_t)((it.x_row >> 1) & 7) : 0u;
   auto reads = [&](int sa, int sb, auto g_) __attribute__((always_inline)) {
     constexpr int GI = decltype(g_)::value;
     read_frags<AT>(fa, laneA + (uint32_t)sa * (uint32_t)kWgSlotBytes + xoff[GI]);
     read_frags<BT>(fb, laneB + (uint32_t)sb * (uint32_t)kWgSlotBytes + xoff[GI]);
+    if constexpr (XR) lds_read16<0>(fe, laneX + (uint32_t)sa * (uint32_t)kWgSlotBytes + 16u * ((uint32_t)(2 * GI + h) ^ swx));
   };
-  auto landed = [&]() __attribute__((always_inline)) { wait_lgkm<0>(); tie_frags<AT>(fa); tie_frags<BT>(fb); };
+  auto landed = [&]() __attribute__((always_inline)) {
+    wait_lgkm<0>(); tie_frags<AT>(fa); tie_frags<BT>(fb);
+    if constexpr (XR) asm volatile("" : "+v"(fe));
+  };
   // half-unit K of the landed k-group -> k-group half HALF of operand set SET (bias sums ride on the A fragments)
   auto half_unit = [&](auto k_, auto half_, auto set_) __attribute__((always_inline)) {
     constexpr int K = decltype(k_)::value, HALF = decltype(half_)::value, SET = decltype(set_)::value;
@@ -211,8 +225,18 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
         split4_by_lo<HALF>(sA[SET][U], fa[U], G);
       }
     } else {
-      if constexpr (PART == 0) split4_hi<HALF>(sB[SET][U - AT], fb[U - AT]);
-      else split4_lo<HALF>(sB[SET][U - AT], fb[U - AT]);
+      if constexpr (PART == 0) {
+        if constexpr (XR) {
+          float d = dsum[U - AT];
+          d = fmaf(fe[0], fb[U - AT][0], d); d = fmaf(fe[1], fb[U - AT][1], d);
+          d = fmaf(fe[2], fb[U - AT][2], d); d = fmaf(fe[3], fb[U - AT][3], d);
+          dsum[U - AT] = d;
+          if constexpr (U == AT) esum += (fe[0] + fe[1]) + (fe[2] + fe[3]);
+        }
+        split4_hi<HALF>(sB[SET][U - AT], fb[U - AT]);
+      } else {
+        split4_lo<HALF>(sB[SET][U - AT], fb[U - AT]);
+      }
     }
   };
   // One block = the MFMAs of the k-step in operand set SET.  With CONV, k-groups GA and GA+1 of the chunk in ring slots
@@ -289,6 +313,16 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
       if (h == 0 && row < it.a_rows) gatomic_add(it.db + row, v);
     }
   }
+  if constexpr (XR) {   // the two lane halves hold different samples of the same B row
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+      const float v = dsum[j] + __shfl_xor(dsum[j], 32);
+      const int col = b_row0 + 32 * j + li;
+      if (wa == 0 && h == 0 && col < it.b_rows) gatomic_add(it.dWx + it.col0 + col, v);
+    }
+    const float e = esum + __shfl_xor(esum, 32);
+    if (wave == 0 && lane == 0 && it.dbx != nullptr) gatomic_add(it.dbx, e);
+  }
 }
 
 #ifdef X3W_STAMPS   // diagnostic build only (scripts/x3w_stamps.py): cycles of every work entry, span of every workgroup
@@ -314,7 +348,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgradItem* __
       case 0x44: wgrad_body<4, 4>(it, smem, wave, lane); break;
       case 0x42: wgrad_body<4, 2>(it, smem, wave, lane); break;
       case 0x41: wgrad_body<4, 1>(it, smem, wave, lane); break;
-      case 0x24: wgrad_body<2, 4>(it, smem, wave, lane); break;
+      case 0x24:
+        if (it.x_row >= 0) wgrad_body<2, 4, true>(it, smem, wave, lane);
+        else wgrad_body<2, 4>(it, smem, wave, lane);
+        break;
       case 0x22: wgrad_body<2, 2>(it, smem, wave, lane); break;
       case 0x21: wgrad_body<2, 1>(it, smem, wave, lane); break;
       case 0x14: wgrad_body<1, 4>(it, smem, wave, lane); break;
