@@ -120,7 +120,7 @@ struct WgradItem {
   // log2 of how many such elements an A value may be the sum of (the per-ray sums of the direction branch)
   const float* amax;
   int32_t amax_shift;
-  // wgrad_f16x3.hip only: an extra VECTOR product that rides on this entry's pass over B -- row x_row of the buffer A
+  // wgrad.hip and wgrad_f16x3.hip: an extra VECTOR product that rides on this entry's pass over B -- row x_row of the buffer A
   // lives in (e.g. d sigma behind the head gradient rows) against every B row: dWx[col0 + j] += sum_m e[m] B[j][m],
   // dbx += sum_m e[m]; fp32 FMAs on the B fragments the waves hold anyway.  x_row < 0: none
   int32_t x_row;

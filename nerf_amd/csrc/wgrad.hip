@@ -58,7 +58,10 @@ template <int N>
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N)); }
 
 // One workgroup = one work entry; wave (wa, wb) owns A tiles [AT*wa, +AT) x B tiles [BT*wb, +BT).
-template <int AT, int BT>
+// XR: the entry carries an extra vector product (WgradItem::x_row): row x_row of A's buffer against every B row, summed
+// with fp32 FMAs on the B fragments the waves hold anyway (the density row behind the head gradient rows: one read
+// of the feature buffer instead of two)
+template <int AT, int BT, bool XR = false>
 __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int wave, int lane) {
   static_assert((AT == 1 || AT == 2 || AT == 4) && (BT == 1 || BT == 2 || BT == 4), "");
   const int li = lane & 31, h = lane >> 5;
@@ -95,12 +98,13 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
   // next to LDS reads): part 0 goes behind the hand-over barrier, parts 1 and 2 into the next chunk's first two
   // k-groups, each among that group's MFMAs; all of them have landed at the next hand-over (vmcnt(0)).
   const int64_t a_step = (int64_t)it.a_stride * 32, b_step = (int64_t)it.b_stride * 32;   // floats per chunk
-  const int nA8 = (it.a_rows + 7) >> 3, nB8 = (it.b_rows + 7) >> 3;
+  const int a_stage = XR ? max(it.a_rows, it.x_row + 1) : it.a_rows;   // rows of A's buffer that are staged
+  const int nA8 = (a_stage + 7) >> 3, nB8 = (it.b_rows + 7) >> 3;
   uint32_t offA[8], offB[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int r = 8 * (wave + 4 * t) + (lane >> 3), sl = (lane & 7) ^ ((r >> 1) & 7);
-    offA[t] = (uint32_t)((min(r, it.a_rows - 1) * 32 + 4 * sl) * 4);   // rows past the end repeat the last row (never stored)
+    offA[t] = (uint32_t)((min(r, a_stage - 1) * 32 + 4 * sl) * 4);   // rows past the end repeat the last row (never stored)
     offB[t] = (uint32_t)((min(r, it.b_rows - 1) * 32 + 4 * sl) * 4);
   }
   // 256x256-class products (AT = BT = 4, 7 of every 8.5 chunks): the pieces are issued BETWEEN the k-steps of the
@@ -128,14 +132,37 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
   __syncthreads();
 
   f32x4 fa[2][AT], fb[2][BT];
+  // XR: the k-group's four samples of the extra vector (the same for every lane of a half), per-B-row sums, its own sum
+  constexpr int NR = AT + BT + (XR ? 1 : 0);   // LDS reads of one k-group
+  f32x4 fe[2];
+  float dsum[BT], esum = 0.f;
+#pragma unroll
+  for (int j = 0; j < BT; ++j) dsum[j] = 0.f;
+  const uint32_t laneX = XR ? lds0 + (uint32_t)it.x_row * 128u : 0u;
+  uint32_t xoffX[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xoffX[g] = XR ? 16u * ((uint32_t)(2 * g + h) ^ (uint32_t)((it.x_row >> 1) & 7)) : 0u;
   auto reads = [&](int set, uint32_t bufoff, int g) {
     if (set == 0) { read_frags<AT>(fa[0], laneA + bufoff + xoff[g]); read_frags<BT>(fb[0], laneB + bufoff + xoff[g]); }
     else          { read_frags<AT>(fa[1], laneA + bufoff + xoff[g]); read_frags<BT>(fb[1], laneB + bufoff + xoff[g]); }
+    if constexpr (XR) {
+      if (set == 0) lds_read16<0>(fe[0], laneX + bufoff + xoffX[g]);
+      else          lds_read16<0>(fe[1], laneX + bufoff + xoffX[g]);
+    }
   };
   // the 4 x AT x BT MFMAs of one k-group; SPREAD and PART >= 0: the staging pieces of part PART of chunk pc are
   // issued between the k-steps (part 0: t = 0,1; part 1: t = 2,3,4; part 2: t = 5,6,7)
-  auto mfmas = [&](f32x4 (&a)[AT], f32x4 (&b)[BT], auto part, int pc, int pbuf) {
+  auto mfmas = [&](f32x4 (&a)[AT], f32x4 (&b)[BT], f32x4& e, auto part, int pc, int pbuf) {
     constexpr int PART = decltype(part)::value;
+    if constexpr (XR) {
+      esum += (e[0] + e[1]) + (e[2] + e[3]);
+#pragma unroll
+      for (int j = 0; j < BT; ++j) {
+        float d = dsum[j];
+        d = fmaf(e[0], b[j][0], d); d = fmaf(e[1], b[j][1], d); d = fmaf(e[2], b[j][2], d); d = fmaf(e[3], b[j][3], d);
+        dsum[j] = d;
+      }
+    }
     if (do_bias) {
 #pragma unroll
       for (int i = 0; i < AT; ++i) bs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
@@ -185,27 +212,34 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
     const bool more = c > c0 && c + 1 < c1;
     const int nbuf = (c + 1 - c0) & 1;
     const int pc1 = min(c + 1, c1 - 1), pc2 = min(c + 2, c1 - 1);
+    auto tie_e = [&](int set) { if constexpr (XR) { if (set == 0) asm volatile("" : "+v"(fe[0])); else asm volatile("" : "+v"(fe[1])); } };
     reads(1, cur, 1);
     burst(P1{}, more, c + 1, nbuf);
-    wait_lgkm<AT + BT>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]);
-    mfmas(fa[0], fb[0], P1{}, pc1, nbuf);
+    wait_lgkm<NR>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]); tie_e(0);
+    mfmas(fa[0], fb[0], fe[0], P1{}, pc1, nbuf);
     reads(0, cur, 2);
     burst(P2{}, more, c + 1, nbuf);
-    wait_lgkm<AT + BT>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]);
-    mfmas(fa[1], fb[1], P2{}, pc1, nbuf);
+    wait_lgkm<NR>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]); tie_e(1);
+    mfmas(fa[1], fb[1], fe[1], P2{}, pc1, nbuf);
     reads(1, cur, 3);
-    wait_lgkm<AT + BT>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]);
-    mfmas(fa[0], fb[0], P_{}, 0, 0);
-    wait_lgkm<0>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]);
+    wait_lgkm<NR>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]); tie_e(0);
+    mfmas(fa[0], fb[0], fe[0], P_{}, 0, 0);
+    wait_lgkm<0>(); tie_frags<AT>(fa[1]); tie_frags<BT>(fb[1]); tie_e(1);
     if (has_next) {
       // every wave is done READING this buffer; chunk c+1 must have landed for all
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       burst(P0{}, c + 2 < c1, c + 2, (c - c0) & 1);
       reads(0, cur ^ (uint32_t)kWgBufBytes, 0);
-      mfmas(fa[1], fb[1], P0{}, pc2, (c - c0) & 1);   // ... all of it behind these MFMAs
+      mfmas(fa[1], fb[1], fe[1], P0{}, pc2, (c - c0) & 1);   // ... all of it behind these MFMAs
+      if constexpr (XR) {
+        // land the next chunk's first reads (issued 32 MFMAs ago) in front of the back edge: with the extra fragment
+        // live across it the compiler copies fragment registers on the loop's exit edge (scripts/check_inflight.py)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkm<0>(); tie_frags<AT>(fa[0]); tie_frags<BT>(fb[0]); tie_e(0);
+      }
     } else {
-      mfmas(fa[1], fb[1], P_{}, 0, 0);
+      mfmas(fa[1], fb[1], fe[1], P_{}, 0, 0);
     }
   };
   reads(0, 0u, 0);
@@ -232,6 +266,16 @@ __device__ __forceinline__ void wgrad_body(const WgradItem& it, float* smem, int
       if (h == 0 && row < it.a_rows) gatomic_add(it.db + row, v);
     }
   }
+  if constexpr (XR) {   // the two lane halves hold different samples of the same B row; the waves with wa == 0 flush
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+      const float v = dsum[j] + __shfl_xor(dsum[j], 32);
+      const int col = b_row0 + 32 * j + li;
+      if (wa == 0 && h == 0 && col < it.b_rows) gatomic_add(it.dWx + it.col0 + col, v);
+    }
+    const float e = esum + __shfl_xor(esum, 32);
+    if (wave == 0 && lane == 0 && it.dbx != nullptr) gatomic_add(it.dbx, e);
+  }
 }
 
 // Persistent workgroup b works through the entries first[b] .. first[b+1]-1 (host: train_impl.inc).
@@ -257,7 +301,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_f32_kernel(const WgradItem* __re
       case 0x44: wgrad_body<4, 4>(it, smem, wave, lane); break;
       case 0x42: wgrad_body<4, 2>(it, smem, wave, lane); break;
       case 0x41: wgrad_body<4, 1>(it, smem, wave, lane); break;
-      case 0x24: wgrad_body<2, 4>(it, smem, wave, lane); break;
+      case 0x24:
+        if (it.x_row >= 0) wgrad_body<2, 4, true>(it, smem, wave, lane);
+        else wgrad_body<2, 4>(it, smem, wave, lane);
+        break;
       case 0x22: wgrad_body<2, 2>(it, smem, wave, lane); break;
       case 0x21: wgrad_body<2, 1>(it, smem, wave, lane); break;
       case 0x14: wgrad_body<1, 4>(it, smem, wave, lane); break;
