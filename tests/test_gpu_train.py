@@ -381,3 +381,32 @@ def test_gradients_other_network_shapes(G, variant, dtype):
     for nm, o_, k in spans:
         assert np.linalg.norm(gr[o_:o_ + k] - rg[o_:o_ + k]) <= 5e-3 * max(np.linalg.norm(rg[o_:o_ + k]), 0.02 * big), nm
     blk.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_gradients_full_ragged_batch(G, dtype):
+    """Full 8x256 network on 37 rays: neither pass fills its last 128-sample tile (37 x 64 and 37 x 192 samples), so the
+    padding columns of every stored operand take part in the weight-gradient products -- including the density row that
+    rides on the head product (WgradItem::x_row) -- and must contribute nothing.  Bars of test_gradients_full."""
+    c = H.CONFIGS["full"]
+    o = Oracle(c)
+    n = 37
+    ro, rd, b, label = H.make_rays(n, 23)
+    params = H.make_params(c, 4)
+    blk = G.make_block(c, max_rays=64, dtype=dtype)      # workspace larger than the batch
+    blk.set_params(params)
+    blk.train_backward(*[x[:16] for x in (ro, rd, b, rd, label)])          # a different batch first: stale store contents
+    lf, lc = blk.train_backward(ro, rd, b, rd, label)
+    gr = blk.get_grads()
+    ref = o.train_grads(params, ro, rd, b, rd, label)
+    assert lf == pytest.approx(ref["loss_fine"], rel=1e-3) and lc == pytest.approx(ref["loss_coarse"], rel=1e-3)
+    rg = ref["grads"]
+    assert np.isfinite(gr).all()
+    assert np.linalg.norm(gr - rg) / np.linalg.norm(rg) < 2e-2
+    off = 0
+    for net in range(2):
+        for nm, r, k in H.layout(c):
+            a, e = gr[off:off + r * k], rg[off:off + r * k]
+            off += r * k
+            assert np.linalg.norm(a) == pytest.approx(np.linalg.norm(e), rel=1e-2), (net, nm)
+    blk.close()
