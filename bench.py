@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--native-rccl", action="store_true", help="data-parallel exchange through the library's own RCCL "
                     "entry points (nerfhip_dp_*: no torch in the step) instead of torch.distributed.all_reduce on the "
                     "gradient buffer; torch.distributed still provides rendezvous, barriers and the max-over-ranks time")
+    ap.add_argument("--extras-at-any-n", action="store_true", help="run the extra single-GPU legs (other dtypes, config 5, "
+                    "800x800 frames, HBM kernels) on every rank at N > 1 as well; by default they run at N = 1 only")
     ap.add_argument("--force-dp", action="store_true", help="take the data-parallel code path (backward, all-reduce, "
                     "optimizer step) even with one rank: rehearsal of the N > 1 loop on a 1-GPU box")
     args = ap.parse_args()
@@ -214,7 +216,16 @@ def main():
     # recorded in the line instead of losing the line (with several ranks it must propagate: the others would hang)
     render_bf16 = render_f16x3 = train_f16x3 = train_bf16 = config5 = render_pose = hbm_kernels = cpu = None
     extras_error = None
+    extras_skipped = None
+
+    class _ExtrasAtN1Only(Exception):
+        pass
+
     try:
+        # the extra legs characterise ONE GPU and do not change with N: at N > 1 they are skipped (every rank would have to
+        # run them in step, and a failure in one of them would cost the scaling run its headline line)
+        if world > 1 and not args.extras_at_any_n:
+            raise _ExtrasAtN1Only()
         # ---- render legs on the other MFMA paths, same frames: bf16 (BASELINE configs[4] arithmetic; parity bar 1e-2 abs,
         # tests/test_gpu_bf16.py) and split-f16 (dtype "f16x3": three f16 MFMAs per product, held to the fp32 parity
         # tests at the fp32 tolerances, tests/test_gpu_render.py) -- reported under their own dtype labels
@@ -425,6 +436,8 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(base, t_o, t_d, t_b, t_l, args.cpu_seconds)
 
+    except _ExtrasAtN1Only:
+        extras_skipped = "the extra single-GPU legs run at N = 1 only (--extras-at-any-n runs them on every rank)"
     except Exception as e:   # noqa: BLE001
         if world > 1:
             raise
@@ -446,7 +459,7 @@ def main():
                 "roofline": roofline, "render": render, "render_bf16": render_bf16, "render_f16x3": render_f16x3,
                 "train_f16x3": train_f16x3, "train_bf16": train_bf16,
                 "config5_bf16": config5, "render_pose_800": render_pose, "hbm_kernels": hbm_kernels,
-                "cpu_baseline": cpu, "extras_error": extras_error}
+                "cpu_baseline": cpu, "extras_error": extras_error, "extras_skipped": extras_skipped}
         print(json.dumps(line))
     if dp:
         dist.destroy_process_group()
