@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16x3": 833.3}   # MI355X_MICROARCH.md: dense MFMA peaks (f16x3: the f16 peak / 3 MFMAs per product)
 
 
 def main():
@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=4096, help="training rays per GPU per step")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16x3"])
     ap.add_argument("--render-frames", type=int, default=3)
     ap.add_argument("--hw", type=int, default=400, help="synthetic image side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -204,6 +204,15 @@ def main():
                 "tflops": {k: round(v[1] / max(v[0], 1e-9) / 1e9, 2) for k, v in kern.items()},
                 "other_ms_per_step": round((prof["composite_ms"] + prof["sampling_ms"] + prof["other_ms"]) / args.steps, 4)}
     roofline.update(pmc_traffic(dom, args.dtype))
+    if args.dtype == "f16x3" and dom == "mlp_wgrad":
+        # the split-f16 weight gradient streams its fp32 operands once per product at the matrix pipe's f16 rate: HBM-bound.
+        # Algorithmic bytes per 32-sample column of both networks: (A rows + B rows) x 128 B over the products
+        # 256x63, 7 x 256x256, 256x63 (skip), 129x256 (head + density row), 3x128
+        rows = (256 + 63) + 7 * (256 + 256) + (256 + 63) + (129 + 256) + (3 + 128)
+        alg = rows * 128.0 * (B * (64 + 192) / 32.0)
+        gbs = alg / max(kern[dom][0] / args.steps, 1e-9) / 1e6
+        roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                         "algorithmic_bytes": round(alg)})
     r_ach = rprof["mlp_fwd_flop"] / max(rprof["mlp_fwd_ms"], 1e-9) / 1e9
     render = {"metric": "rays/sec (render)", "value": round(render_rays_s, 1), "unit": "rays/s",
               "workload": f"{HW}x{HW} frame, {n_frame} rays/GPU/frame", "frames": args.render_frames,
@@ -471,19 +480,20 @@ def pmc_traffic(dom, dtype):
     units KB; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect
     counters itself, so this is read from profiles/; null when the summaries are absent."""
     import csv
-    sub = {"mlp_wgrad": "wgrad_%s_kernel", "mlp_fwd": "mlp_fwd_%s_kernel<8, 1, true>" if dtype == "bf16" else "mlp_fwd_%s_kernel<8, true>",
+    sub = {"mlp_wgrad": "wgrad_%s_kernel", "mlp_fwd": "mlp_fwd_%s_kernel<8, true>" if dtype == "f32" else "mlp_fwd_%s_kernel<8, 1, true>",
            "mlp_bwd": "mlp_bwd_%s_kernel"}[dom] % dtype
+    tag = "f16x3train" if dtype == "f16x3" else dtype
     tot = 0.0
     try:
         for kind, col, mul in (("fetchsize", "FETCH_SIZE", 2.0), ("writesize", "WRITE_SIZE", 1.0)):
-            path = os.path.join(ROOT, "profiles", f"r2_final_{dtype}_pmc_{kind}.csv")
+            path = os.path.join(ROOT, "profiles", f"r2_final_{tag}_pmc_{kind}.csv")
             for r in csv.DictReader(open(path)):
                 if sub in r["kernel"]:
                     tot += mul * float(r[col]) * 1024.0 / 3.0     # 3 profiled steps
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
     return {"traffic": round(tot), "traffic_unit": "bytes per train step (all launches of the kernel)",
-            "traffic_source": f"profiles/r2_final_{dtype}_pmc_fetchsize.csv, _writesize.csv"}
+            "traffic_source": f"profiles/r2_final_{tag}_pmc_fetchsize.csv, _writesize.csv"}
 
 
 def hbm_traffic(kname):
