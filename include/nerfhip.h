@@ -40,7 +40,13 @@ enum {
  * fp32 accumulation (renders within 1e-2 abs).  F16X3: split-f16 operands (every operand = hi + lo, two f16 halves; three
  * f16 MFMAs per product, fp32 accumulation; weights must stay below 1023 in magnitude) in the render AND the training
  * kernels: fp32-grade results -- held to the same parity tests and tolerances as F32 -- at about 3x the F32 render rate
- * and 2.3x the F32 training rate; parameters, gradients and optimizer state stay fp32. */
+ * and 2.3x the F32 training rate; parameters, gradients and optimizer state stay fp32.
+ * F16X3 range (enforced, never silent): the operands are f16 pairs of 64*w and of the activations, so a weight with
+ * |w| >= 1023.5 (or non-finite) and an activation beyond 65504 have no representation.  nerfhip_set_params rejects such
+ * weights with NERFHIP_E_INVALID and names the tensor; weights that LEAVE the range in an optimizer step, and activations
+ * that overflow in a forward pass (the network's outputs turn non-finite), raise a device flag that the next synchronising
+ * call on the handle -- nerfhip_synchronize, get_params, the host-pointer render / train entry points, a _dev training
+ * call that returns its loss -- reports as NERFHIP_E_INVALID (and clears).  The remedy is dtype F32. */
 enum { NERFHIP_F32 = 0, NERFHIP_BF16 = 1, NERFHIP_F16X3 = 2 };
 
 /* Mirrors the arithmetic-relevant fields of nerf/nerfConfig.scala:20-43 (same meaning, same order),
@@ -149,6 +155,12 @@ int nerfhip_render_u8(nerfhip_t* h, const float* rays_o, const float* rays_d, co
  * rendered in blocks of max_rays.  Replaces the H per-row evaluate calls and the upload of H*W*32 bytes of rays. */
 int nerfhip_render_pose_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w_host, float near,
                            float far, int32_t ndc, uint8_t* out);
+/* Rows [row0, row1) of that image: renderToImage's row loop (runNerf.scala:187-199: one evaluate per image ROW, rows
+ * stacked in order) cut into contiguous row blocks, one block per GPU -- BASELINE configs[2], "rays sharded across 8 GPUs".
+ * out host [row1-row0][W][3]; the blocks of all ranks, stacked in rank order, ARE nerfhip_render_pose_u8's image bit for
+ * bit (rays are independent; there is no collective on this path).  row0 == row1 renders nothing and succeeds. */
+int nerfhip_render_pose_rows_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w_host, float near,
+                                float far, int32_t ndc, int32_t row0, int32_t row1, uint8_t* out);
 
 /* ---- training ------------------------------------------------------------------------------- */
 /* trainer.forward(inputs) in training mode (runNerf.scala:100): fine and coarse rgb, [n][3] each

@@ -64,6 +64,7 @@ SYMBOLS = {
     "nerfhip_render_static_max_rays": (_I64, [_P]),
     "nerfhip_render_u8": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P]),
     "nerfhip_render_pose_u8": (C.c_int, [_P, _I32, _I32, _F, _P, _F, _F, _I32, _P]),
+    "nerfhip_render_pose_rows_u8": (C.c_int, [_P, _I32, _I32, _F, _P, _F, _F, _I32, _I32, _I32, _P]),
     "nerfhip_forward_train": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, C.POINTER(Aux)]),
     "nerfhip_train_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, C.POINTER(Aux)]),
     "nerfhip_train_backward_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, C.POINTER(Aux)]),

@@ -195,6 +195,16 @@ class NerfBlock:
         self._chk(rc, "render_pose_u8")
         return out
 
+    def render_pose_rows(self, H, W, focal, c2w, near, far, ndc, row0, row1):
+        """Rows [row0, row1) of that image (nerfhip_render_pose_rows_u8): one rank's block of a frame whose rows are
+        sharded over the GPUs; uint8 (row1 - row0, W, 3)."""
+        c2w = _f32(np.asarray(c2w)[:3, :4], (3, 4))
+        out = np.empty((max(row1 - row0, 0), W, 3), np.uint8)
+        rc = self._lib.nerfhip_render_pose_rows_u8(self._h, int(H), int(W), float(focal), _ptr(c2w), float(near),
+                                                   float(far), int(ndc), int(row0), int(row1), _ptr(out))
+        self._chk(rc, "render_pose_rows_u8")
+        return out
+
     # ---- training (host arrays)
     def train_backward(self, rays_o, rays_d, bounds, view_dir, label, rand=None, debug=False):
         """trainer.forward + calculateLoss + collector.backward (runNerf.scala:100-103).

@@ -98,11 +98,13 @@ struct nerfhip {
   float *w_zf = nullptr, *w_sigf = nullptr, *w_wf = nullptr, *w_crawf = nullptr;
   float *w_trand = nullptr, *w_urand = nullptr, *w_noisec = nullptr, *w_noisef = nullptr;
   uint8_t* w_u8 = nullptr;
-  double* d_loss = nullptr;  // [2]
+  double* d_loss = nullptr;  // [3]: fine and coarse loss sums; [2] = 8 bytes of scratch for dp_broadcast_state's update count
   bool train_ws = false;
   nh::WgradItem* d_items = nullptr;
   nh::WgradBfItem* d_bitems = nullptr;   // bf16 path
   std::vector<nh::WgradBfItem> bitems;
+  uint32_t* d_x3flags = nullptr;      // dtype f16x3 range guard: [net] = flat index + 1 of a weight with |64 w| >= 65504 (pack.hip),
+                                      // [2] = a forward kernel wrote a non-finite output (mlp_fwd_f16x3.hip); see check_x3_range
   float* d_amax = nullptr;            // dtype f16x3: [2][kMaxD + 2] largest gradient elements of the step (mlp_bwd_f16x3.hip)
   int32_t* d_items_first = nullptr;   // [n workgroups + 1] first work entry of every persistent workgroup
   std::vector<int32_t> items_first;
@@ -377,9 +379,9 @@ int repack(nerfhip* h) {
     }
     HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
     if (h->cfg.dtype == NERFHIP_F16X3) {   // the split-f16 kernels' pair streams (forward, density-only, backward)
-      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->stream));
-      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, h->stream));
-      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_bwd_desc, (int)n.x3_bwd.size(), n.d_x3_bwd, h->stream));
+      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->d_x3flags + i, h->stream));
+      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, nullptr, h->stream));
+      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_bwd_desc, (int)n.x3_bwd.size(), n.d_x3_bwd, nullptr, h->stream));
       HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, 64.0f, h->stream));
     }
   }
@@ -406,7 +408,7 @@ int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const floa
     st.Mpad = (nr * S + kTile - 1) / kTile * kTile;
     HIPCHK(h, launch_mlp_fwd_f16x3(net_args(h, n), want_rgb ? n.d_x3_full : n.d_x3_sigma, n.d_bvec, o, d, z, n.d_dirfeat, nr * S, S,
                                    sigma, craw, want_rgb ? 1 : 0, (int)((want_rgb ? n.x3_full.size() : n.x3_sigma.size()) / 16),
-                                   h->n_cu, train_store ? &st : nullptr, h->stream));
+                                   h->n_cu, train_store ? &st : nullptr, h->d_x3flags + 2, h->stream));
   } else if (h->cfg.dtype == NERFHIP_BF16) {
     BfStore bst = n.bst;
     bst.Mpad = (nr * S + 255) / 256 * 256;
@@ -524,6 +526,42 @@ nerfhip_aux aux_slice(const nerfhip_aux* a, int64_t off, int N, int S) {
   return s;
 }
 
+// name of the parameter tensor that holds flat index `at` of one network (DJL child order, include/nerfhip.h)
+std::string param_name(const NetLayout& L, int64_t at) {
+  auto in = [&](int64_t off, int64_t cnt) { return at >= off && at < off + cnt; };
+  for (int l = 0; l < L.D; ++l) {
+    if (in(L.w_off[l], (int64_t)L.W * L.fan_in[l])) return "trunk layer " + std::to_string(l) + " weight";
+    if (in(L.b_off[l], L.W)) return "trunk layer " + std::to_string(l) + " bias";
+  }
+  if (in(L.ws_off, L.W)) return "density head weight";
+  if (in(L.wf_off, (int64_t)L.head_rows * L.W)) return "colour head first matrix";
+  if (L.mode == 1 && in(L.wd_off, (int64_t)L.H2 * L.Ed)) return "view-direction matrix";
+  if (L.mode == 1 && in(L.wc_off, 3 * L.H2)) return "colour output matrix";
+  return "parameter";
+}
+
+// dtype f16x3 range guard, called by every entry point that synchronises anyway (the asynchronous _dev entry points are
+// covered by the next such call, e.g. nerfhip_synchronize): the split-f16 operands hold 64 w and the activations as f16
+// (hi, lo) pairs, so |w| >= 1023.5 or an activation beyond 65504 has no representation.  The kernels flag both instead
+// of silently producing inf; this turns a raised flag into NERFHIP_E_INVALID and clears it.  `h->stream` must be idle.
+int check_x3_range(nerfhip* h) {
+  if (h->cfg.dtype != NERFHIP_F16X3 || !h->d_x3flags) return NERFHIP_OK;
+  uint32_t f[4] = {0, 0, 0, 0};
+  HIPCHK(h, hipMemcpyAsync(f, h->d_x3flags, sizeof(f), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!(f[0] | f[1] | f[2])) return NERFHIP_OK;
+  HIPCHK(h, hipMemsetAsync(h->d_x3flags, 0, sizeof(f), h->stream));
+  for (int i = 0; i < h->nnets; ++i)
+    if (f[i]) {
+      const int64_t at = (int64_t)f[i] - 1;
+      return fail(h, NERFHIP_E_INVALID, "dtype f16x3: a weight of network " + std::to_string(i) + " (" + param_name(h->nets[i].L, at) +
+                                            ", flat index " + std::to_string(h->nets[i].param_off + at) +
+                                            ") is non-finite or reaches |w| >= 1023.5, beyond the split-f16 operand range (use dtype f32)");
+    }
+  return fail(h, NERFHIP_E_INVALID, "dtype f16x3: an activation left the f16 operand range (|x| > 65504) and the network produced non-finite "
+                                    "outputs; the results of the calls since the last check are invalid (use dtype f32 for these weights)");
+}
+
 int check_handle(nerfhip* h) {
   if (!h) return fail(nullptr, NERFHIP_E_INVALID, "null handle");
   hipError_t e = hipSetDevice(h->cfg.device);
@@ -540,8 +578,6 @@ int check_handle(nerfhip* h) {
 #include "dp_rccl.inc"
 
 extern "C" {
-
-const char* nerfhip_version(void) { return "nerfhip 0.2 (gfx950; fp32, bf16 and split-f16 MFMA)"; }
 
 const char* nerfhip_last_error(const nerfhip_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -616,7 +652,7 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
   CCHK(hipMemsetAsync(h->d_grads, 0, h->nparams * sizeof(float), h->stream));
   CCHK(hipMemsetAsync(h->d_m, 0, h->nparams * sizeof(float), h->stream));
   CCHK(hipMemsetAsync(h->d_v, 0, h->nparams * sizeof(float), h->stream));
-  CCHK(dalloc(&h->d_loss, 2));
+  CCHK(dalloc(&h->d_loss, 3));
   for (int i = 0; i < h->nnets; ++i) {
     Net& n = h->nets[i];
     n.L = L;
@@ -674,6 +710,10 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
       CCHK(hipMemsetAsync(n.d_x3_full, 0, (2 * n.x3_full.size() + padf) * 1024, h->stream));
       CCHK(hipMemsetAsync(n.d_x3_sigma, 0, (2 * n.x3_sigma.size() + padf) * 1024, h->stream));
       CCHK(dalloc(&n.d_bvec, (size_t)L.D * L.W + 5 * 32 + 32));
+      if (!h->d_x3flags) {
+        CCHK(dalloc(&h->d_x3flags, 4));
+        CCHK(hipMemsetAsync(h->d_x3flags, 0, 4 * sizeof(uint32_t), h->stream));
+      }
     }
     CCHK(dalloc(&n.d_dirfeat, (size_t)h->R * std::max(32 * n.HT, 12)));
   }
@@ -700,7 +740,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->dp_comm) nerfhip_dp_destroy(h);
   auto fr = [](void* p) { if (p) hipFree(p); };
-  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems); fr(h->d_amax);
+  fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems); fr(h->d_amax); fr(h->d_x3flags);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
     fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_bwd_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.d_x3_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
@@ -727,7 +767,7 @@ int nerfhip_set_stream(nerfhip_t* h, void* s) {
 int nerfhip_synchronize(nerfhip_t* h) {
   int rc = check_handle(h); if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return NERFHIP_OK;
+  return check_x3_range(h);   // what the asynchronous calls since the last check flagged (dtype f16x3)
 }
 
 int64_t nerfhip_param_count(const nerfhip_t* h) { return h ? h->nparams : 0; }
@@ -737,7 +777,9 @@ int nerfhip_set_params(nerfhip_t* h, const float* src, int64_t n) {
   if (!src || n != h->nparams) return fail(h, NERFHIP_E_INVALID, "set_params: wrong size");
   HIPCHK(h, hipMemcpyAsync(h->d_params, src, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return repack(h);
+  rc = repack(h);
+  if (rc) return rc;
+  return check_x3_range(h);   // dtype f16x3: weights beyond the split-f16 range are rejected here, by name
 }
 
 int nerfhip_get_params(nerfhip_t* h, float* dst, int64_t n) {
@@ -745,7 +787,7 @@ int nerfhip_get_params(nerfhip_t* h, float* dst, int64_t n) {
   if (!dst || n != h->nparams) return fail(h, NERFHIP_E_INVALID, "get_params: wrong size");
   HIPCHK(h, hipMemcpyAsync(dst, h->d_params, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return NERFHIP_OK;
+  return check_x3_range(h);
 }
 
 int nerfhip_init_params(nerfhip_t* h, uint64_t seed) {
@@ -885,7 +927,7 @@ int nerfhip_render(nerfhip_t* h, const float* o, const float* d, const float* b,
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
-  return NERFHIP_OK;
+  return check_x3_range(h);
 }
 
 int nerfhip_render_u8(nerfhip_t* h, const float* o, const float* d, const float* b, const float* v, int64_t n,
@@ -903,15 +945,20 @@ int nerfhip_render_u8(nerfhip_t* h, const float* o, const float* d, const float*
     HIPCHK(h, hipMemcpyAsync(out + off * 3, h->w_u8, nr * 3, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
-  return NERFHIP_OK;
+  return check_x3_range(h);
 }
 
-int nerfhip_render_pose_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w, float near, float far,
-                           int32_t ndc, uint8_t* out) {
+// rows [row0, row1) of the image: one rank's shard of a frame whose rows are spread over several GPUs (BASELINE
+// configs[2]); the whole frame is rows [0, H)
+int nerfhip_render_pose_rows_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w, float near, float far,
+                                int32_t ndc, int32_t row0, int32_t row1, uint8_t* out) {
   int rc = check_handle(h); if (rc) return rc;
-  if (!c2w || !out || H <= 0 || W <= 0 || !(focal > 0.f)) return fail(h, NERFHIP_E_INVALID, "render_pose_u8: bad argument");
-  const int64_t n = (int64_t)H * W;
-  if (h->pose_rays_cap < n) {   // frame-sized ray buffers, kept for the next frame of this size
+  if (!c2w || H <= 0 || W <= 0 || !(focal > 0.f)) return fail(h, NERFHIP_E_INVALID, "render_pose_u8: bad argument");
+  if (row0 < 0 || row1 < row0 || row1 > H) return fail(h, NERFHIP_E_INVALID, "render_pose_rows_u8: rows must satisfy 0 <= row0 <= row1 <= H");
+  const int64_t n = (int64_t)(row1 - row0) * W;
+  if (n == 0) return NERFHIP_OK;       // a rank without rows (more ranks than rows) renders nothing
+  if (!out) return fail(h, NERFHIP_E_INVALID, "render_pose_u8: null output");
+  if (h->pose_rays_cap < n) {   // block-sized ray buffers, kept for the next call of this size
     if (h->d_pose_rays) { HIPCHK(h, hipFree(h->d_pose_rays)); h->d_pose_rays = nullptr; h->pose_rays_cap = 0; }
     HIPCHK(h, hipMalloc((void**)&h->d_pose_rays, (size_t)n * 8 * sizeof(float)));
     h->pose_rays_cap = n;
@@ -919,7 +966,7 @@ int nerfhip_render_pose_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, cons
   float* ro = h->d_pose_rays;
   float* rd = ro + n * 3;
   float* bd = rd + n * 3;
-  HIPCHK(h, launch_gen_rays(H, W, focal, c2w, near, far, ndc, ro, rd, bd, h->stream));
+  HIPCHK(h, launch_gen_rays(H, W, focal, c2w, near, far, ndc, row0, row1 - row0, ro, rd, bd, h->stream));
   for (int64_t off = 0; off < n; off += h->R) {
     const int64_t nr = std::min<int64_t>(h->R, n - off);
     DevIn in{ro + off * 3, rd + off * 3, bd + off * 2, rd + off * 3, nullptr, nullptr, nullptr, nullptr};
@@ -929,7 +976,13 @@ int nerfhip_render_pose_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, cons
     HIPCHK(h, hipMemcpyAsync(out + off * 3, h->w_u8, nr * 3, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));   // w_u8 is reused by the next block
   }
-  return NERFHIP_OK;
+  return check_x3_range(h);
+}
+
+int nerfhip_render_pose_u8(nerfhip_t* h, int32_t H, int32_t W, float focal, const float* c2w, float near, float far,
+                           int32_t ndc, uint8_t* out) {
+  if (h && !out) return fail(h, NERFHIP_E_INVALID, "render_pose_u8: bad argument");
+  return nerfhip_render_pose_rows_u8(h, H, W, focal, c2w, near, far, ndc, 0, H, out);
 }
 
 int nerfhip_forward_train(nerfhip_t* h, const float* o, const float* d, const float* b, const float* v, int64_t n,
@@ -954,7 +1007,7 @@ int nerfhip_forward_train(nerfhip_t* h, const float* o, const float* d, const fl
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
-  return NERFHIP_OK;
+  return check_x3_range(h);
 }
 
 // ---- single kernels -------------------------------------------------------------------------------
@@ -1009,7 +1062,7 @@ int nerfhip_k_gen_rays(nerfhip_t* h, int32_t H, int32_t W, float focal, const fl
                        int32_t ndc, float* rays_o, float* rays_d, float* bounds) {
   int rc = check_handle(h); if (rc) return rc;
   if (H < 1 || W < 1 || !c2w || !rays_o || !rays_d || !bounds) return fail(h, NERFHIP_E_INVALID, "k_gen_rays: bad argument");
-  HIPCHK(h, launch_gen_rays(H, W, focal, c2w, near, far, ndc, rays_o, rays_d, bounds, h->stream));
+  HIPCHK(h, launch_gen_rays(H, W, focal, c2w, near, far, ndc, 0, H, rays_o, rays_d, bounds, h->stream));
   return NERFHIP_OK;
 }
 

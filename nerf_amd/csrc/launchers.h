@@ -16,8 +16,8 @@ hipError_t launch_composite_bwd(const float* sigma, const float* noise, const fl
 hipError_t launch_sample_pdf(const float* w, const float* z, const float* u_rand, int64_t n, int N, int NI, int perturb,
                              uint64_t seed, uint32_t step, float* cdf, int32_t* ind, float* zs, float* z_fine,
                              hipStream_t s);
-hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float near, float far, int use_ndc,
-                           float* rays_o, float* rays_d, float* bounds, hipStream_t s);
+hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float near, float far, int use_ndc, int row0,
+                           int nrows, float* rays_o, float* rays_d, float* bounds, hipStream_t s);
 hipError_t launch_to_u8(const float* rgb, int64_t n, uint8_t* out, hipStream_t s);
 hipError_t launch_random(uint64_t seed, uint32_t stream, uint32_t step, int64_t n, int normal, float* out, hipStream_t s);
 size_t composite_bwd_lds_bytes(int S);
@@ -73,11 +73,12 @@ hipError_t prepare_wgrad_bf16();
 hipError_t prepare_mlp_fwd_bf16(int W, int mode);
 hipError_t prepare_mlp_bwd_bf16(int W, int mode);
 // split-f16 render path (mlp_fwd_f16x3.hip, pack.hip)
-hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s);
+hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, int n, void* dst, uint32_t* flag, hipStream_t s);
 hipError_t prepare_mlp_fwd_f16x3(int W, int mode);
 hipError_t launch_mlp_fwd_f16x3(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                 const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                                float* craw, int want_rgb, int nblk, int n_cu, const ActStore* st, hipStream_t stream);
+                                float* craw, int want_rgb, int nblk, int n_cu, const ActStore* st, uint32_t* nonfinite_flag,
+                                hipStream_t stream);
 // mlp_bwd_f16x3.hip: backward-data pass of a training step with dtype f16x3 (reads/writes the fp32 activation store)
 hipError_t prepare_mlp_bwd_f16x3(int W, int mode);
 // amax: [D + 2] floats of this network, zeroed by the caller: slot l = largest |dY_l| written, slot D = largest

@@ -95,11 +95,16 @@ struct EpiTrunk {   // relu + split -> B operand pairs of the next layer; piece 
     }
   }
 };
+// range guard (f16x3_common.hip.h: activations beyond f16's 65504 have no high half): an overflowed activation is +inf,
+// survives the ReLU and reaches the network's outputs as inf / NaN (unless every weight behind it is exactly zero), so the
+// outputs are where it is looked for: one integer test per written value, OR-ed into a register the kernel publishes once
+__device__ __forceinline__ uint32_t nonfinite_bits(float v) { return (__builtin_bit_cast(uint32_t, v) & 0x7f800000u) == 0x7f800000u ? 1u : 0u; }
+
 struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
-  float* sigma; int m; bool valid; int h;
+  float* sigma; int m; bool valid; int h; uint32_t& bad;
   static constexpr int kPieces = 1;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
-    if (valid && h == 0) sigma[m] = a[0] * kWInv;
+    if (valid && h == 0) { sigma[m] = a[0] * kWInv; bad |= nonfinite_bits(a[0]); }
   }
 };
 template <int HT, int MODE, bool TRAIN>
@@ -109,11 +114,12 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
   Ring& rg;
   StoreCtx sc;      // TRAIN, mode 1: the colour hidden layer (ActStore::hc) and its sign bits (slot D)
   uint32_t mw;
+  uint32_t& bad;
   static constexpr int kPieces = 8;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
     if constexpr (OT_IDX == HT) {
       if constexpr (P == 0)
-        if (valid && h == 0) sigma[m] = a[0] * kWInv;
+        if (valid && h == 0) { sigma[m] = a[0] * kWInv; bad |= nonfinite_bits(a[0]); }
     } else if constexpr (MODE == 1) {
       // add().relu() (nerfCoreBlock.scala:67): + (Wd.enc(dir) + bd + bf) of the sample's ray, fp32; registers 2P, 2P+1
       // hold features 32 OT + 8 (P/2) + 2 (P%2) + 4h + {0, 1}
@@ -188,7 +194,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
                                                                        const float* __restrict__ z,
                                                                        const float* __restrict__ dirfeat, int64_t M, int S,
                                                                        float* __restrict__ sigma, float* __restrict__ craw,
-                                                                       int want_rgb, int nblk, int ntiles, ActStore st) {
+                                                                       int want_rgb, int nblk, int ntiles, ActStore st,
+                                                                       uint32_t* __restrict__ nonfinite_flag) {
   constexpr int R = 32 * WT;
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring (kRing x 32 KiB) | vectors
@@ -219,6 +226,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
 #else
 #define STAMP(i)
 #endif
+  uint32_t bad = 0u;   // range guard: this lane wrote a non-finite output
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     STAMP(0);
     const int m = tile * kTileSamples + wave * 32 + li;   // host guarantees M < 2^31
@@ -275,14 +283,14 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     const uint32_t haddr = vec_addr + (uint32_t)(D * R) * 4u;
     if (!want_rgb) {
       // sigma-only stream: one tile, row 0 = density row (nerfCoreBlock.scala:39-40)
-      EpiSigma epi{sigma, m, valid, h};
+      EpiSigma epi{sigma, m, valid, h, bad};
       run_part<2 * WT, 1, true, TRAIN>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, nullptr}, epi);
       continue;
     }
     // head: HT colour tiles, then the density tile
     ActRegs<HT> hid;
     float c[3] = {0.f, 0.f, 0.f};
-    EpiHead<HT, MODE, TRAIN> epih{hid, c, dirfeat, ray, m, valid, sigma, h, rg, store_ctx(st.hc, 32 * HT, D), 0u};
+    EpiHead<HT, MODE, TRAIN> epih{hid, c, dirfeat, ray, m, valid, sigma, h, rg, store_ctx(st.hc, 32 * HT, D), 0u, bad};
     STAMP(10);
     run_part<2 * WT, HT + 1, true, TRAIN>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
     STAMP(11);
@@ -297,8 +305,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
 #if NERFHIP_DIAG_STAMPS
     ++it;
 #endif
-    if (valid && h == 0) { craw[(int64_t)m * 3 + 0] = c[0]; craw[(int64_t)m * 3 + 1] = c[1]; craw[(int64_t)m * 3 + 2] = c[2]; }
+    if (valid && h == 0) {
+      craw[(int64_t)m * 3 + 0] = c[0]; craw[(int64_t)m * 3 + 1] = c[1]; craw[(int64_t)m * 3 + 2] = c[2];
+      bad |= nonfinite_bits(c[0]) | nonfinite_bits(c[1]) | nonfinite_bits(c[2]);
+    }
   }   // tile loop
+  if (bad && nonfinite_flag) atomicOr(nonfinite_flag, 1u);
 #if NERFHIP_DIAG_STAMPS
   if (blockIdx.x == 5 && tid == 0) for (int i = 0; i < 13; ++i) reinterpret_cast<uint64_t*>(craw)[i] = st[i];
 #endif
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
 template <int WT, int MODE>
 static hipError_t launch_one(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o, const float* rays_d,
                              const float* z, const float* dirfeat, int64_t M, int S, float* sigma, float* craw, int want_rgb,
-                             int nblk, int n_cu, const ActStore* st, hipStream_t stream) {
+                             int nblk, int n_cu, const ActStore* st, uint32_t* nonfinite_flag, hipStream_t stream) {
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   const size_t lds = (size_t)kRing * kBlkBytes + ((size_t)net.D * 32 * WT + (HT + 1) * 32 + 32) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -316,10 +328,10 @@ static hipError_t launch_one(const NetArgs& net, const void* stream_w, const flo
   const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kWaves);   // one persistent workgroup per CU
   if (st)
     hipLaunchKernelGGL((mlp_fwd_f16x3_kernel<WT, MODE, true>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
-                       rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles, *st);
+                       rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles, *st, nonfinite_flag);
   else
     hipLaunchKernelGGL((mlp_fwd_f16x3_kernel<WT, MODE, false>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
-                       rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles, ActStore{});
+                       rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles, ActStore{}, nonfinite_flag);
   return hipGetLastError();
 }
 
@@ -351,10 +363,11 @@ hipError_t prepare_mlp_fwd_f16x3(int W, int mode) {
 // st: the fp32 activation store to fill (training forward), or null
 hipError_t launch_mlp_fwd_f16x3(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                 const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
-                                float* craw, int want_rgb, int nblk, int n_cu, const ActStore* st, hipStream_t stream) {
+                                float* craw, int want_rgb, int nblk, int n_cu, const ActStore* st, uint32_t* nonfinite_flag,
+                                hipStream_t stream) {
   const int W = net.W, mode = net.mode;
 #define NH_X3_LAUNCH(WT_, MODE_) \
-  return x3::launch_one<WT_, MODE_>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, st, stream)
+  return x3::launch_one<WT_, MODE_>(net, stream_w, bvec, rays_o, rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, n_cu, st, nonfinite_flag, stream)
   NH_X3_CASES(NH_X3_LAUNCH)
 #undef NH_X3_LAUNCH
 }

@@ -45,9 +45,11 @@ __device__ __forceinline__ void pack_frag_bf16(const float* __restrict__ params,
 }
 // split-f16 weight streams (f16x3_common.hip.h): descriptor i -> fragment 2i = hi = f16(64 w), fragment 2i+1 = lo =
 // f16(64 w - hi); same lane / element order as the bf16 fragments
+// range guard: an element with |64 w| >= 65504 has no f16 high half (it would become inf); its flat index + 1 goes into
+// *flag (largest offender wins), nerfhip_set_params / the next synchronising call turn that into NERFHIP_E_INVALID
 __global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __restrict__ params,
                                                               const FragDesc* __restrict__ descs,
-                                                              _Float16* __restrict__ dst) {
+                                                              _Float16* __restrict__ dst, uint32_t* __restrict__ flag) {
   const FragDesc d = descs[blockIdx.x];
   const int lane = threadIdx.x, h = lane >> 5, i = lane & 31;
   const float* src = params + (d.src_off < 0 ? 0 : d.src_off);
@@ -58,9 +60,13 @@ __global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __res
   for (int e = 0; e < 8; ++e) {
     const int f = 16 * d.s + (e & 3) + 8 * (e >> 2) + 4 * h;
     float v = 0.f;
-    if (d.src_off >= 0 && row < d.nrows && f < d.kvalid)
-      v = d.transposed ? src[(int64_t)(d.col0 + f) * d.ld + row] : src[(int64_t)row * d.ld + d.col0 + f];
+    int64_t at = -1;
+    if (d.src_off >= 0 && row < d.nrows && f < d.kvalid) {
+      at = d.transposed ? (int64_t)(d.col0 + f) * d.ld + row : (int64_t)row * d.ld + d.col0 + f;
+      v = src[at];
+    }
     const float vs = __fmul_rn(v, 64.0f);   // exact
+    if (!(fabsf(vs) < 65504.0f) && at >= 0 && flag) atomicMax(flag, (uint32_t)(d.src_off + at) + 1u);   // also catches NaN
     const _Float16 hi = (_Float16)vs;
     oh[e] = hi;
     ol[e] = (_Float16)(__fsub_rn(vs, (float)hi));
@@ -261,9 +267,9 @@ hipError_t launch_repack_bf16(const RepackBf16Args& a, hipStream_t s) {
   hipLaunchKernelGGL(repack_bf16_kernel, dim3(a.nfrag + a.nnets * RepackBf16Args::kBvecBlocks), dim3(64), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, int n, void* dst, hipStream_t s) {
+hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, int n, void* dst, uint32_t* flag, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_frags_f16x3_kernel, dim3(n), dim3(64), 0, s, params, descs, (_Float16*)dst);
+  hipLaunchKernelGGL(pack_frags_f16x3_kernel, dim3(n), dim3(64), 0, s, params, descs, (_Float16*)dst, flag);
   return hipGetLastError();
 }
 hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, float scale, hipStream_t s) {

@@ -610,11 +610,14 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 struct Pose { float m[12]; };
 
-__global__ void gen_rays_kernel(int H, int Wd, float focal, Pose c2w, float near, float far, int use_ndc,
+// rows [row0, row0 + nrows) of the H x Wd image; output index p = (j - row0) * Wd + i (a rank's row block of a sharded frame
+// starts at the head of its own buffers)
+__global__ void gen_rays_kernel(int H, int Wd, float focal, Pose c2w, float near, float far, int use_ndc, int row0, int nrows,
                                 float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ bounds) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= (int64_t)H * Wd) return;
-  const int j = (int)(p / Wd), i = (int)(p - (int64_t)j * Wd);
+  if (p >= (int64_t)nrows * Wd) return;
+  const int jl = (int)(p / Wd), i = (int)(p - (int64_t)jl * Wd);
+  const int j = row0 + jl;
   const float halfW = (float)(Wd * .5), halfH = (float)(H * .5);
   const float dir0 = __fdiv_rn(__fsub_rn((float)i, halfW), focal);
   const float dir1 = -__fdiv_rn(__fsub_rn((float)j, halfH), focal);
@@ -743,13 +746,15 @@ hipError_t launch_sample_pdf(const float* w, const float* z, const float* u_rand
   return hipGetLastError();
 }
 
-hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float near, float far, int use_ndc,
-                           float* rays_o, float* rays_d, float* bounds, hipStream_t s) {
+hipError_t launch_gen_rays(int H, int Wd, float focal, const float* c2w, float near, float far, int use_ndc, int row0,
+                           int nrows, float* rays_o, float* rays_d, float* bounds, hipStream_t s) {
+  if (row0 < 0 || nrows < 0 || row0 + nrows > H) return hipErrorInvalidValue;
+  if (nrows == 0) return hipSuccess;
   Pose p;
   for (int i = 0; i < 12; ++i) p.m[i] = c2w[i];
-  const int64_t total = (int64_t)H * Wd;
+  const int64_t total = (int64_t)nrows * Wd;
   hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, H, Wd, focal, p, near,
-                     far, use_ndc, rays_o, rays_d, bounds);
+                     far, use_ndc, row0, nrows, rays_o, rays_d, bounds);
   return hipGetLastError();
 }
 

@@ -52,6 +52,17 @@ def row_block(H, rank, world):
     return r0, r0 + base + (1 if rank < rem else 0)
 
 
+def render_sharded_frame(block, H, W, focal, c2w, near, far, ndc=False, rank=0, world=1, gather=None):
+    """ONE H x W frame rendered by `world` ranks (BASELINE configs[2]): this rank renders `row_block(H, rank, world)`
+    from the pose (rays made on the device, nerfhip_render_pose_rows_u8) -- no collective on the data path -- and
+    `gather(rows_u8 [rows][W][3]) -> [H][W][3]` stacks the blocks in rank order (DataParallel.gather_rows; None = return
+    this rank's block).  The stacked image equals the single-GPU frame bit for bit (runNerf.scala:187-199: rows are
+    evaluated independently and stacked in order)."""
+    r0, r1 = row_block(H, rank, world)
+    rows = block.render_pose_rows(H, W, focal, c2w, near, far, ndc, r0, r1)
+    return rows if gather is None else gather(rows)
+
+
 def split_batch(n, rank, world):
     """Batch.split(devices, false) (runNerf.scala:95): slice [i0, i1) of an n-ray batch owned by `rank`."""
     return row_block(n, rank, world)

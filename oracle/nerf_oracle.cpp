@@ -727,6 +727,7 @@ void forward_impl(const orc_config* c, const float* params, bool training, int64
     st.z_f.resize((size_t)B * S);
     orc_sample_pdf(c, B, st.w_c.data(), st.z_c.data(), io ? io->u_rand : nullptr, io ? io->cdf : nullptr,
                    io ? io->ind : nullptr, io ? io->z_samples : nullptr, st.z_f.data());
+    if (io && io->z_fine_in) memcpy(st.z_f.data(), io->z_fine_in, sizeof(float) * (size_t)B * S);   // test hook, nerf_oracle.h
   } else {
     st.z_f = st.z_c;
   }

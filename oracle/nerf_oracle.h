@@ -75,6 +75,12 @@ typedef struct orc_io {
   float* sigma_f;     /* [B][S] */
   float* craw_c;      /* [B][N][3] raw colour (training only for coarse) */
   float* craw_f;      /* [B][S][3] */
+  /* test hook (last, so that the layout above is unchanged): when non-NULL and hierarchical, these fine depths replace the
+   * resampler's output for the rest of the pass (fine network, compositing, loss, backward).  samplePdf carries no gradient
+   * (stopGradient, nerfBlock.scala:81), so the pass from the fine depths on is a function of (params, z_fine) alone: a test
+   * can hand in the DEVICE's fine depths and compare everything behind the sampler without the sampler's `den < 1e-5`
+   * discontinuity in the way (the sampler itself is compared bit for bit on identical inputs elsewhere). */
+  const float* z_fine_in;   /* [B][S] */
 } orc_io;
 
 int64_t orc_net_param_count(const orc_config* c);   /* one network */

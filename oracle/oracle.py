@@ -34,7 +34,7 @@ class OrcIO(C.Structure):
     _fields_ = [(n, _FP) for n in ("t_rand", "u_rand", "noise_c", "noise_f", "rgb_fine", "rgb_coarse",
                                    "depth", "acc", "z_coarse", "w_coarse", "cdf")] + \
                [("ind", _IP)] + \
-               [(n, _FP) for n in ("z_samples", "z_fine", "w_fine", "sigma_c", "sigma_f", "craw_c", "craw_f")]
+               [(n, _FP) for n in ("z_samples", "z_fine", "w_fine", "sigma_c", "sigma_f", "craw_c", "craw_f", "z_fine_in")]
 
 
 def build(force=False):
@@ -213,6 +213,11 @@ class Oracle:
             setattr(io, k, _f(a) if a is not None else None)
         for k, a in out.items():
             setattr(io, k, a.ctypes.data_as(_IP) if k == "ind" else _f(a))
+        zin = rand.get("z_fine_in")   # test hook (nerf_oracle.h): the rest of the pass at THESE fine depths
+        if zin is not None:
+            zin = _arr(zin, (B, S))
+            keep.append(zin)
+            io.z_fine_in = _f(zin)
         return io, out, keep
 
     def forward(self, params, rays_o, rays_d, bounds, viewdir, training=False, rand=None):

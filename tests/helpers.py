@@ -141,3 +141,26 @@ def make_rays(B, seed=0, radius=4.0, near=2.0, far=6.0):
     label = u[:, 5:8]
     f32 = np.float32
     return o.astype(f32), d.astype(f32), bounds.astype(f32), label.astype(f32)
+
+
+def param_spans(c):
+    """[(network, tensor name, offset, count)] of the flat parameter / gradient vector"""
+    out, off = [], 0
+    for net in range(2 if c["useHierarchical"] else 1):
+        for nm, r, k in layout(c):
+            out.append((net, nm, off, r * k))
+            off += r * k
+    return out
+
+
+def assert_grads_close(c, gr, rg, whole=1e-3, per_tensor=5e-3, floor=0.02):
+    """Whole gradient vector within `whole` (relative L2) and EVERY tensor within `per_tensor` of its own norm -- or of
+    `floor` x the largest tensor's norm for the tiny ones (a bias, the density row), so that a wrong small tensor cannot
+    hide behind the large ones the way a norm-vs-norm comparison lets it."""
+    assert np.isfinite(gr).all()
+    assert np.linalg.norm(gr - rg) / np.linalg.norm(rg) < whole, np.linalg.norm(gr - rg) / np.linalg.norm(rg)
+    spans = param_spans(c)
+    big = max(np.linalg.norm(rg[o:o + k]) for _, _, o, k in spans)
+    for net, nm, o, k in spans:
+        err = np.linalg.norm(gr[o:o + k] - rg[o:o + k])
+        assert err <= per_tensor * max(np.linalg.norm(rg[o:o + k]), floor * big), (net, nm, err, np.linalg.norm(rg[o:o + k]))

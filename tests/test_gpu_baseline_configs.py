@@ -14,7 +14,7 @@ import pytest
 import gpu_util as G
 import helpers as H
 from nerf_amd import blender as B
-from nerf_amd.dp import row_block
+from nerf_amd.dp import render_sharded_frame, row_block
 from oracle.oracle import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -69,5 +69,30 @@ def test_config2_row_sharded_frame_equals_whole_frame(dtype):
             parts.append(blk.render_u8(ro[s], rd[s], bd[s], rd[s]).reshape(r1 - r0, Wimg, 3))
             rows = r1
         np.testing.assert_array_equal(np.concatenate(parts, 0), whole)
+    finally:
+        blk.close()
+
+
+@pytest.mark.parametrize("dtype,world", [("f32", 8), ("bf16", 8), ("f16x3", 3)])
+def test_config2_pose_rows_of_a_faked_world_stack_to_the_whole_frame(dtype, world):
+    """bench.py's `render_sharded_800` leg (nerf_amd.dp.render_sharded_frame over nerfhip_render_pose_rows_u8): every rank
+    of a faked world renders its row block of ONE frame straight from the pose; stacked in rank order the blocks equal the
+    single-call frame bit for bit -- including a world that does not divide the rows (800 = 267 + 267 + 266) and blocks
+    larger than max_rays."""
+    c = dict(H.CONFIGS["full"], dtype=dtype)
+    Himg, Wimg = 800, 12
+    focal = 0.5 * 800 / math.tan(0.5 * ANGLE)
+    pose = B.get_render_poses(1.3, math.pi / 6, 4.0)
+    blk = G.make_block(c, max_rays=1000)
+    blk.init_params(4)
+    try:
+        whole = blk.render_pose(Himg, Wimg, focal, pose, 2.0, 6.0, False)
+        parts = [render_sharded_frame(blk, Himg, Wimg, focal, pose, 2.0, 6.0, False, rank, world) for rank in range(world)]
+        assert [p.shape[0] for p in parts] == [row_block(Himg, r, world)[1] - row_block(Himg, r, world)[0] for r in range(world)]
+        np.testing.assert_array_equal(np.concatenate(parts, 0), whole)
+        assert blk.render_pose_rows(Himg, Wimg, focal, pose, 2.0, 6.0, False, 5, 5).shape == (0, Wimg, 3)   # a rank without rows
+        from nerf_amd import NerfHipError
+        with pytest.raises(NerfHipError):
+            blk.render_pose_rows(Himg, Wimg, focal, pose, 2.0, 6.0, False, 10, Himg + 1)
     finally:
         blk.close()

@@ -90,8 +90,13 @@ def test_gradients_small(G, case, dtype):
 
 @pytest.mark.parametrize("dtype", ["f32", "f16x3"])
 def test_gradients_full(G, dtype):
-    """Full 8x256 coarse+fine network, 64 rays: per-tensor gradient norms vs oracle within 1e-2 (end to end,
-    see the sensitivity note in test_oracle_golden.py) and whole-vector relative L2 error < 2e-2."""
+    """Full 8x256 coarse+fine network, 64 rays, against the oracle's hand-written backward.  The sampler is compared bit
+    for bit on identical inputs elsewhere (test_gpu_render.py); end to end a last-bit difference in a coarse weight can
+    move ONE fine sample across the `den < 1e-5` branch of samplePdf, so the oracle is evaluated at the DEVICE's fine
+    depths (orc_io.z_fine_in: samplePdf carries no gradient, nerfBlock.scala:81) and everything behind the sampler is held
+    to what the kernels deliver: whole gradient < 1e-4 relative, every tensor within 5e-3 of its own norm (or of 2 % of the
+    largest tensor's).  Against the oracle at its OWN fine depths: whole gradient < 1e-3, and no fine depth off by more
+    than one coarse bin."""
     c = H.CONFIGS["full"]
     o = Oracle(c)
     n = 64
@@ -99,18 +104,46 @@ def test_gradients_full(G, dtype):
     params = H.make_params(c, 2)
     blk = G.make_block(c, max_rays=n, dtype=dtype)
     blk.set_params(params)
-    lf, lc = blk.train_backward(ro, rd, b, rd, label)
+    lf, lc, dbg = blk.train_backward(ro, rd, b, rd, label, debug=True)
     gr = blk.get_grads()
+    at_dev = o.train_grads(params, ro, rd, b, rd, label, rand={"z_fine_in": dbg["z_fine"]})
+    assert lf == pytest.approx(at_dev["loss_fine"], rel=1e-5) and lc == pytest.approx(at_dev["loss_coarse"], rel=1e-5)
+    H.assert_grads_close(c, gr, at_dev["grads"], whole=1e-4)
     ref = o.train_grads(params, ro, rd, b, rd, label)
     assert lf == pytest.approx(ref["loss_fine"], rel=1e-3) and lc == pytest.approx(ref["loss_coarse"], rel=1e-3)
+    H.assert_grads_close(c, gr, ref["grads"], whole=1e-3)
+    bin_w = np.diff(ref["z_coarse"], axis=1).max(axis=1, keepdims=True)
+    assert (np.abs(dbg["z_fine"] - ref["z_fine"]) <= bin_w).all()
+    blk.close()
+
+
+def test_f16x3_colour_output_gradient_with_a_small_colour_matrix(G):
+    """on the full W = 256 view-direction network the density row rides on the head product (shape 0x24) and the
+    3 x H2 colour-output item used to take its operand scale from amax slot D (max |d colour-hidden pre-activation|) although
+    its A operand is d craw (slot D+1).  With Wc scaled by 1e-3, max |d craw| is ~1000 x max |dh|: the old scale put G * d craw
+    beyond 65504 -> inf halves -> NaN dWc / dbc.  Now: finite and within the fp32 tolerance of the oracle."""
+    c = H.CONFIGS["full"]
+    o = Oracle(c)
+    n = 48
+    ro, rd, b, label = H.make_rays(n, 27)
+    params = H.make_params(c, 6)
+    spans = {(net, nm): (off, k) for net, nm, off, k in H.param_spans(c)}
+    for net in (0, 1):
+        off, k = spans[(net, "wc")]
+        params[off:off + k] *= 1e-3
+    blk = G.make_block(c, max_rays=n, dtype="f16x3")
+    blk.set_params(params)
+    lf, lc, dbg = blk.train_backward(ro, rd, b, rd, label, debug=True)
+    gr = blk.get_grads()
+    assert np.isfinite(gr).all()
+    ref = o.train_grads(params, ro, rd, b, rd, label, rand={"z_fine_in": dbg["z_fine"]})
     rg = ref["grads"]
-    assert np.linalg.norm(gr - rg) / np.linalg.norm(rg) < 2e-2
-    off = 0
-    for net in range(2):
-        for nm, r, k in H.layout(c):
-            a, e = gr[off:off + r * k], rg[off:off + r * k]
-            off += r * k
-            assert np.linalg.norm(a) == pytest.approx(np.linalg.norm(e), rel=1e-2), (net, nm)
+    for net in (0, 1):
+        for nm in ("wc", "bc", "wf", "ws"):
+            off, k = spans[(net, nm)]
+            err = np.linalg.norm(gr[off:off + k] - rg[off:off + k])
+            assert err <= 5e-3 * np.linalg.norm(rg[off:off + k]), (net, nm, err, np.linalg.norm(rg[off:off + k]))
+    H.assert_grads_close(c, gr, rg, whole=1e-3)
     blk.close()
 
 
@@ -387,7 +420,8 @@ def test_gradients_other_network_shapes(G, variant, dtype):
 def test_gradients_full_ragged_batch(G, dtype):
     """Full 8x256 network on 37 rays: neither pass fills its last 128-sample tile (37 x 64 and 37 x 192 samples), so the
     padding columns of every stored operand take part in the weight-gradient products -- including the density row that
-    rides on the head product (WgradItem::x_row) -- and must contribute nothing.  Bars of test_gradients_full."""
+    rides on the head product (WgradItem::x_row) -- and must contribute nothing.  Bars of test_gradients_full (whole gradient
+    < 1e-4 at the device's fine depths, < 1e-3 at the oracle's own, every tensor within 5e-3)."""
     c = H.CONFIGS["full"]
     o = Oracle(c)
     n = 37
@@ -396,17 +430,12 @@ def test_gradients_full_ragged_batch(G, dtype):
     blk = G.make_block(c, max_rays=64, dtype=dtype)      # workspace larger than the batch
     blk.set_params(params)
     blk.train_backward(*[x[:16] for x in (ro, rd, b, rd, label)])          # a different batch first: stale store contents
-    lf, lc = blk.train_backward(ro, rd, b, rd, label)
+    lf, lc, dbg = blk.train_backward(ro, rd, b, rd, label, debug=True)
     gr = blk.get_grads()
+    at_dev = o.train_grads(params, ro, rd, b, rd, label, rand={"z_fine_in": dbg["z_fine"]})     # see test_gradients_full
+    assert lf == pytest.approx(at_dev["loss_fine"], rel=1e-5) and lc == pytest.approx(at_dev["loss_coarse"], rel=1e-5)
+    H.assert_grads_close(c, gr, at_dev["grads"], whole=1e-4)
     ref = o.train_grads(params, ro, rd, b, rd, label)
     assert lf == pytest.approx(ref["loss_fine"], rel=1e-3) and lc == pytest.approx(ref["loss_coarse"], rel=1e-3)
-    rg = ref["grads"]
-    assert np.isfinite(gr).all()
-    assert np.linalg.norm(gr - rg) / np.linalg.norm(rg) < 2e-2
-    off = 0
-    for net in range(2):
-        for nm, r, k in H.layout(c):
-            a, e = gr[off:off + r * k], rg[off:off + r * k]
-            off += r * k
-            assert np.linalg.norm(a) == pytest.approx(np.linalg.norm(e), rel=1e-2), (net, nm)
+    H.assert_grads_close(c, gr, ref["grads"], whole=1e-3)
     blk.close()
