@@ -70,16 +70,32 @@ __device__ __forceinline__ float* uniform_ptr(float* p) {
 template <int POS>
 __device__ __forceinline__ uint32_t sign_bit_at(float v) { return (uint32_t)min(__builtin_bit_cast(int, v), 1) << POS; }
 
+// Range guard (f16x3_common.hip.h: an activation beyond f16's 65504 has no high half).  An overflowed activation becomes
+// hi = +inf, lo = -inf, the next layer's accumulators NaN -- and a NaN with its sign bit set is a negative integer that the
+// ReLU turns into 0, so the network would quietly go on with zeros (measured: every output = its bias).  The overflow is
+// therefore caught where it happens: every freshly made pair of high halves goes through ONE v_pk_max_u16 into a running
+// maximum (post-ReLU halves are non-negative, so as unsigned 16-bit patterns inf = 0x7c00 and NaN > 0x7c00 are the
+// largest values); signed inputs (the encoding) drop their sign bits first.  The outputs are tested as well (one integer
+// test per written value).  Everything is OR-ed into one register that the kernel publishes once, at its end.
+__device__ __forceinline__ uint32_t nonfinite_bits(float v) { return (__builtin_bit_cast(uint32_t, v) & 0x7f800000u) == 0x7f800000u ? 1u : 0u; }
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void track_hi(uint32_t& mx, uint32_t h) {
+  mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, mx), __builtin_bit_cast(u16x2, h)));
+}
+__device__ __forceinline__ uint32_t hi_overflowed(uint32_t mx) { return ((mx & 0xffffu) >= 0x7c00u || (mx >> 16) >= 0x7c00u) ? 1u : 0u; }
+
 template <int WT, bool TRAIN>
 struct EpiTrunk {   // relu + split -> B operand pairs of the next layer; piece P = registers 2P, 2P+1 of the tile
   ActRegs<WT>& out;
   Ring& rg;
   StoreCtx sc;
   uint32_t mw;
+  uint32_t& mx;     // range guard: running maximum of the high halves made
   static constexpr int kPieces = 8;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
     if constexpr (!TRAIN) {
       split_scaled_into(out.v[OT_IDX][P / 4], P % 4, relu_bits(a[2 * P]), relu_bits(a[2 * P + 1]));
+      track_hi(mx, out.v[OT_IDX][P / 4].hi[P % 4]);
     } else {
       const float v0 = relu_bits(a[2 * P]) * kWInv, v1 = relu_bits(a[2 * P + 1]) * kWInv;   // exact: a power of two
       store_reg<OT_IDX, 2 * P>(sc.dst, sc.voff, v0);
@@ -92,14 +108,10 @@ struct EpiTrunk {   // relu + split -> B operand pairs of the next layer; piece 
         rg.note(1);
       }
       split_into(out.v[OT_IDX][P / 4], P % 4, v0, v1);
+      track_hi(mx, out.v[OT_IDX][P / 4].hi[P % 4]);
     }
   }
 };
-// range guard (f16x3_common.hip.h: activations beyond f16's 65504 have no high half): an overflowed activation is +inf,
-// survives the ReLU and reaches the network's outputs as inf / NaN (unless every weight behind it is exactly zero), so the
-// outputs are where it is looked for: one integer test per written value, OR-ed into a register the kernel publishes once
-__device__ __forceinline__ uint32_t nonfinite_bits(float v) { return (__builtin_bit_cast(uint32_t, v) & 0x7f800000u) == 0x7f800000u ? 1u : 0u; }
-
 struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
   float* sigma; int m; bool valid; int h; uint32_t& bad;
   static constexpr int kPieces = 1;
@@ -115,6 +127,7 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
   StoreCtx sc;      // TRAIN, mode 1: the colour hidden layer (ActStore::hc) and its sign bits (slot D)
   uint32_t mw;
   uint32_t& bad;
+  uint32_t& bad_mx;   // range guard: running maximum of the high halves made (colour hidden layer)
   static constexpr int kPieces = 8;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(const f32x16& a) {
     if constexpr (OT_IDX == HT) {
@@ -138,6 +151,7 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
         }
       }
       split_into(hid.v[OT_IDX][P / 4], P % 4, v0, v1);
+      track_hi(bad_mx, hid.v[OT_IDX][P / 4].hi[P % 4]);
     } else if constexpr (MODE == 2) {
       // reshape(...,9,3).mul(SH).sum(-2) (:55): c[k] = sum_j q[3j+k] * Y_j(dir); rows 0..26 of tile 0
       const float* Y = dirfeat + (int64_t)ray * 12;
@@ -172,7 +186,7 @@ struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
 // positionCode (nerfCoreBlock.scala:127-136) of this lane's 32 of the 64 (padded) features, split into operand pairs
 // (element 2i, 2i+1 of k-step s of k-tile kt = accumulator-layout register 8s + 2i, 8s + 2i + 1 of tile kt)
 template <bool RED, bool TRAIN, int KT = 0, int S_ = 0, int I = 0>
-__device__ __forceinline__ void encode(ActRegs<2>& enc, float px, float py, float pz, int E, int h, const StoreCtx& sc) {
+__device__ __forceinline__ void encode(ActRegs<2>& enc, float px, float py, float pz, int E, int h, const StoreCtx& sc, uint32_t& mx) {
   if constexpr (KT < 2) {
     const float v0 = code_value_h<RED>(px, py, pz, 32 * KT + feature(S_, 0, 2 * I), h, E);
     const float v1 = code_value_h<RED>(px, py, pz, 32 * KT + feature(S_, 0, 2 * I + 1), h, E);
@@ -181,8 +195,9 @@ __device__ __forceinline__ void encode(ActRegs<2>& enc, float px, float py, floa
       store_reg<KT, 8 * S_ + 2 * I + 1>(sc.dst, sc.voff, v1);
     }
     split_into(enc.v[KT][S_], I, v0, v1);
+    if constexpr (KT == 0 && S_ == 0 && I < 2) track_hi(mx, enc.v[KT][S_].hi[I] & 0x7fff7fffu);   // the raw position (rows 0..2): the only unbounded rows
     constexpr int nxt = (KT * 2 + S_) * 4 + I + 1;
-    encode<RED, TRAIN, nxt / 8, (nxt / 4) % 2, nxt % 4>(enc, px, py, pz, E, h, sc);
+    encode<RED, TRAIN, nxt / 8, (nxt / 4) % 2, nxt % 4>(enc, px, py, pz, E, h, sc, mx);
   }
 }
 
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
 #else
 #define STAMP(i)
 #endif
-  uint32_t bad = 0u;   // range guard: this lane wrote a non-finite output
+  uint32_t bad = 0u, mx = 0u;   // range guard: this lane wrote a non-finite output / running maximum of the f16 high halves made
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     STAMP(0);
     const int m = tile * kTileSamples + wave * 32 + li;   // host guarantees M < 2^31
@@ -250,20 +265,20 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     ActRegs<2> enc;
     {
       const StoreCtx sce = store_ctx(st.enc, 64, 0);
-      if (trig_reduced(px, py, pz, net.E)) encode<true, TRAIN>(enc, px, py, pz, net.E, h, sce);   // wave-uniform: the usual case
-      else encode<false, TRAIN>(enc, px, py, pz, net.E, h, sce);
+      if (trig_reduced(px, py, pz, net.E)) encode<true, TRAIN>(enc, px, py, pz, net.E, h, sce, mx);   // wave-uniform: the usual case
+      else encode<false, TRAIN>(enc, px, py, pz, net.E, h, sce, mx);
       if constexpr (TRAIN) rg.note(32);
     }
 
     STAMP(1);
     ActRegs<WT> act, nxt;
     {
-      EpiTrunk<WT, TRAIN> epi{act, rg, store_ctx(st.act, R, 0), 0u};
+      EpiTrunk<WT, TRAIN> epi{act, rg, store_ctx(st.act, R, 0), 0u, mx};
       run_part<4, WT, true, TRAIN>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
     }
     STAMP(2);
     auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) __attribute__((always_inline)) {
-      EpiTrunk<WT, TRAIN> epi{out, rg, store_ctx(st.act + (int64_t)l * R * st.Mpad, R, l), 0u};
+      EpiTrunk<WT, TRAIN> epi{out, rg, store_ctx(st.act + (int64_t)l * R * st.Mpad, R, l), 0u, mx};
       const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
       if ((net.skip_mask >> (l - 1)) & 1u) run_part<2 * WT + 4, WT, true, TRAIN>(rg, baddr, SelAct<WT>{in, &enc}, epi);
       else run_part<2 * WT, WT, true, TRAIN>(rg, baddr, SelAct<WT>{in, nullptr}, epi);
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
     // head: HT colour tiles, then the density tile
     ActRegs<HT> hid;
     float c[3] = {0.f, 0.f, 0.f};
-    EpiHead<HT, MODE, TRAIN> epih{hid, c, dirfeat, ray, m, valid, sigma, h, rg, store_ctx(st.hc, 32 * HT, D), 0u, bad};
+    EpiHead<HT, MODE, TRAIN> epih{hid, c, dirfeat, ray, m, valid, sigma, h, rg, store_ctx(st.hc, 32 * HT, D), 0u, bad, mx};
     STAMP(10);
     run_part<2 * WT, HT + 1, true, TRAIN>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
     STAMP(11);
@@ -310,6 +325,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
       bad |= nonfinite_bits(c[0]) | nonfinite_bits(c[1]) | nonfinite_bits(c[2]);
     }
   }   // tile loop
+  bad |= hi_overflowed(mx);
   if (bad && nonfinite_flag) atomicOr(nonfinite_flag, 1u);
 #if NERFHIP_DIAG_STAMPS
   if (blockIdx.x == 5 && tid == 0) for (int i = 0; i < 13; ++i) reinterpret_cast<uint64_t*>(craw)[i] = st[i];
