@@ -108,6 +108,12 @@ template <int IMM>
 __device__ __forceinline__ void lds_read_f4(f32x4& d, uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
 }
+// These waits are NOT optional timing hints.  The compiler considers the destination of an asm ds_read written at the
+// statement and re-uses the same physical VGPRs afterwards -- in the inference kernel 56 of the 186 fragment-destination
+// registers double as address operands of global loads / stores / LDS-DMA -- so a fragment that lands late overwrites
+// whatever lives there by then: garbage operands at best, a memory fault when it is an address (a development build with
+// these waits compiled out faulted the GPU, scripts/README.md).  scripts/check_inflight.py proves on the final ISA that no
+// instruction reads or writes such a register while its load may be outstanding.
 template <int N>
 __device__ __forceinline__ void wait_lgkm_n() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N)); }
 

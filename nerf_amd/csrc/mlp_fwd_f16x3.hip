@@ -236,8 +236,8 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
   rg.start();
 
 #if NERFHIP_DIAG_STAMPS
-  uint64_t st[16]; int it = 0;
-#define STAMP(i) do { if (it == 3) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  uint64_t stamp_t[16]; int it = 0;
+#define STAMP(i) do { if (it == 3) stamp_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i)
 #endif
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) void mlp_fwd_f16x3_kernel(NetArgs n
   bad |= hi_overflowed(mx);
   if (bad && nonfinite_flag) atomicOr(nonfinite_flag, 1u);
 #if NERFHIP_DIAG_STAMPS
-  if (blockIdx.x == 5 && tid == 0) for (int i = 0; i < 13; ++i) reinterpret_cast<uint64_t*>(craw)[i] = st[i];
+  if (blockIdx.x == 5 && tid == 0) for (int i = 0; i < 13; ++i) reinterpret_cast<uint64_t*>(craw)[i] = stamp_t[i];
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }

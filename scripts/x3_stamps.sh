@@ -7,5 +7,8 @@ cd "$(dirname "$0")/../nerf_amd/csrc"
 make -s
 mkdir -p ../../build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DNERFHIP_DIAG_STAMPS=1 -c mlp_fwd_f16x3.hip -o /tmp/x3_stamps.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/libnerfhip_stamps.so api.o mlp_fwd.o mlp_bwd.o /tmp/x3_stamps.o mlp_fwd_bf16.o mlp_bwd_bf16.o wgrad_bf16.o wgrad.o ray_kernels.o pack.o -ldl
+# every object of the product library except the forward kernel's, plus the instrumented one (as scripts/x3w_stamps.sh links:
+# api.o references all kernels' launchers, so a hand-kept object list goes stale)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/libnerfhip_stamps.so $(ls *.o | grep -v "^mlp_fwd_f16x3.o$") /tmp/x3_stamps.o -ldl
+python3 -c "import ctypes; ctypes.CDLL('../../build/libnerfhip_stamps.so', mode=ctypes.RTLD_NOW)"   # all symbols resolve
 echo build/libnerfhip_stamps.so
