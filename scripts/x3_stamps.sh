@@ -10,5 +10,5 @@ mkdir -p ../../build
 # every object of the product library except the forward kernel's, plus the instrumented one (as scripts/x3w_stamps.sh links:
 # api.o references all kernels' launchers, so a hand-kept object list goes stale)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/libnerfhip_stamps.so $(ls *.o | grep -v "^mlp_fwd_f16x3.o$") /tmp/x3_stamps.o -ldl
-python3 -c "import ctypes; ctypes.CDLL('../../build/libnerfhip_stamps.so', mode=ctypes.RTLD_NOW)"   # all symbols resolve
+python3 -c "import ctypes, os; ctypes.CDLL('../../build/libnerfhip_stamps.so', mode=os.RTLD_NOW)"   # all symbols resolve
 echo build/libnerfhip_stamps.so
