@@ -25,20 +25,32 @@ namespace nh {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kNS = 1;                 // sample tiles (of 32) per wave
-constexpr int kBfWaves = 8;            // waves per workgroup: 2 per SIMD (256 registers each), so one wave's epilogue
-                                       // VALU work and LDS waits hide behind the other's MFMAs
-constexpr int kBfTile = kBfWaves * kNS * 32;  // samples per workgroup
 constexpr int kBlkFrags = 32;
 constexpr int kBlkBytes = kBlkFrags * 1024;
+// Tiling of a kernel: NS sample tiles (of 32) per wave, WAVES waves per workgroup (256 samples either way).
+//   <1, 8>  two waves per SIMD (256 registers each): one wave's epilogue VALU work and LDS waits hide behind the other's
+//           MFMAs; every wave reads a 1-KiB fragment out of LDS per MFMA -- the training kernels (their stores assume it);
+//   <2, 4>  one wave per SIMD (512 registers), every fragment feeds TWO MFMAs (both sample tiles): half the LDS read
+//           traffic per MFMA -- the inference forward kernel, whose LDS read port was as busy as its matrix pipe.
+template <int NS_, int WAVES_>
+struct BfCfg {
+  static constexpr int NS = NS_, WAVES = WAVES_;
+  static constexpr int TILE = WAVES_ * NS_ * 32;          // samples per workgroup
+  static constexpr int DMA = kBlkBytes / WAVES_ / 1024;   // LDS-DMA instructions per wave per block
+};
+using BfCfg1 = BfCfg<1, 8>;
+constexpr int kNS = BfCfg1::NS;                // the training kernels' tiling, by its old names
+constexpr int kBfWaves = BfCfg1::WAVES;
+constexpr int kBfTile = BfCfg1::TILE;
 constexpr int kRing = 4;
-constexpr int kPD = 4;                 // fragments fetched ahead
+#ifndef NH_BF_PD
+#define NH_BF_PD 4
+#endif
+constexpr int kPD = NH_BF_PD;           // fragments fetched ahead
 constexpr int kSyncFrag = kBlkFrags - kPD - 1;   // position of the sync point inside a block (before the prefetch crosses into the next)
 
 // feature (inside a 32-feature tile) held by element e of k-step s in lane half h
 __device__ __host__ constexpr int bf_feature(int s, int h, int e) { return 16 * s + (e & 3) + 8 * (e >> 2) + 4 * h; }
-
-constexpr int kDmaPieces = kBlkBytes / kBfWaves / 1024;   // LDS-DMA instructions per wave per block
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n >= 4 (rounded down to a supported count: stricter, never weaker)
 __device__ __forceinline__ void wait_vm_at_most(int n) {
@@ -54,7 +66,8 @@ __device__ __forceinline__ void wait_vm_at_most(int n) {
   else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 
-struct BfRing {
+template <class C>
+struct BfRingT {
   const char* stream;   // packed fragments (global), nblk blocks; consumed cyclically (persistent workgroups start
                         // the next sample tile on block 0 again while the ring keeps running)
   float* ring;          // LDS ring, slot 0
@@ -71,10 +84,10 @@ struct BfRing {
   int young_a, young_b;
   __device__ __forceinline__ void note(int n) { young_b += n; }
   __device__ __forceinline__ void request() {
-    const char* src = stream + (size_t)req_src * kBlkBytes + wave * (kBlkBytes / kBfWaves) + lane * 16;
-    char* dst = reinterpret_cast<char*>(ring) + (req & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / kBfWaves);
+    const char* src = stream + (size_t)req_src * kBlkBytes + wave * (kBlkBytes / C::WAVES) + lane * 16;
+    char* dst = reinterpret_cast<char*>(ring) + (req & (kRing - 1)) * kBlkBytes + wave * (kBlkBytes / C::WAVES);
 #pragma unroll
-    for (int p = 0; p < kDmaPieces; ++p)
+    for (int p = 0; p < C::DMA; ++p)
       __builtin_amdgcn_global_load_lds(NERFHIP_GPTR(src + p * 1024), NERFHIP_LPTR(dst + p * 1024), 16, 0, 0);
     asm volatile("" ::: "memory");   // no later memory operation may be issued in front of the pieces
     ++req;
@@ -85,13 +98,13 @@ struct BfRing {
     blk = 0; req = 0; req_src = 0;
     asm volatile("" ::: "memory");
     request(); request(); request();
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kDmaPieces) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * C::DMA) : "memory");
     __builtin_amdgcn_s_barrier();
     young_a = young_b = 0;
   }
   // sync point P_blk: block blk+1 visible to every wave, slot of block blk-1 handed to block blk+3
   __device__ __forceinline__ void sync_point() {
-    wait_vm_at_most(young_a + kDmaPieces + young_b);
+    wait_vm_at_most(young_a + C::DMA + young_b);
     __builtin_amdgcn_s_barrier();
     request();
     young_a = young_b;
@@ -99,6 +112,7 @@ struct BfRing {
   }
   __device__ __forceinline__ uint32_t slot_addr(int b) const { return ring_addr + (uint32_t)(b & (kRing - 1)) * kBlkBytes; }
 };
+using BfRing = BfRingT<BfCfg1>;
 
 template <int IMM>
 __device__ __forceinline__ void lds_read_frag(bf16x8& d, uint32_t addr) {
@@ -137,7 +151,7 @@ __device__ __forceinline__ f32x16 bias_value(BiasBuf& b) {   // call only behind
 
 // ---- one layer part: OT output tiles x KS k-steps, fragments j = ot*KS + ks ---------------------------------
 // BSel:  template <int KS_IDX> const bf16x8& b(int n) const      B operand of k-step KS_IDX for sample tile n
-// Epi:   static constexpr int kPieces;  template <int OT_IDX, int P> void piece(f32x16 (&acc)[kNS])
+// Epi:   static constexpr int kPieces;  template <int OT_IDX, int P> void piece(f32x16 (&acc)[NS])
 //        the epilogue of a finished output tile, cut into kPieces pieces which are spread over the k-steps of the
 //        NEXT tile (accumulators are double buffered), so its VALU work issues between that tile's MFMAs instead
 //        of stalling on the last MFMA's result with the matrix pipe idle; the last tile's pieces run at the end.
@@ -165,21 +179,22 @@ struct PartSched {
 
 template <int KS, int NP>
 constexpr int piece_offset(int p) { return (p * KS) / NP + (KS >= 8 ? 1 : 0); }
-template <int KS, class Epi, int OT_IDX, int OFF, int P = 0>
+template <int NS, int KS, class Epi, int OT_IDX, int OFF, int P = 0>
 struct EpiPieces {   // runs the pieces of tile OT_IDX scheduled at k-step offset OFF (OFF < 0: all)
-  static __device__ __forceinline__ void run(Epi& epi, f32x16 (&acc)[kNS]) {
+  static __device__ __forceinline__ void run(Epi& epi, f32x16 (&acc)[NS]) {
     if constexpr (P < Epi::kPieces) {
       if constexpr (OFF < 0 || piece_offset<KS, Epi::kPieces>(P) == OFF) epi.template piece<OT_IDX, P>(acc);
-      EpiPieces<KS, Epi, OT_IDX, OFF, P + 1>::run(epi, acc);
+      EpiPieces<NS, KS, Epi, OT_IDX, OFF, P + 1>::run(epi, acc);
     }
   }
 };
 
-template <int KS, int OT, class BSel, class Epi, bool BIAS, int J>
+template <class C, int KS, int OT, class BSel, class Epi, bool BIAS, int J>
 struct PartStep {
   using S = PartSched<KS, OT, BIAS>;
-  static __device__ __forceinline__ void run(BfRing& rg, int blk0, uint32_t bias_addr, bf16x8 (&fr)[kPD + 1], BiasBuf& bias,
-                                             f32x16 (&acc)[2][kNS], const BSel& bsel, Epi& epi) {
+  static constexpr int kNS = C::NS;
+  static __device__ __forceinline__ void run(BfRingT<C>& rg, int blk0, uint32_t bias_addr, bf16x8 (&fr)[kPD + 1], BiasBuf& bias,
+                                             f32x16 (&acc)[2][C::NS], const BSel& bsel, Epi& epi) {
     constexpr int ot = J / KS, ks = J % KS;
     if constexpr (J + kPD < S::NF) {
       constexpr int jj = J + kPD;
@@ -203,10 +218,10 @@ struct PartStep {
       for (int n = 0; n < kNS; ++n)
         acc[ot & 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[J % (kPD + 1)], bsel.template b<ks>(n), acc[ot & 1][n], 0, 0, 0);
     }
-    if constexpr (ot >= 1) EpiPieces<KS, Epi, ot - 1, ks>::run(epi, acc[(ot - 1) & 1]);
-    if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<KS, Epi, ot, -1>::run(epi, acc[ot & 1]);
+    if constexpr (ot >= 1) EpiPieces<C::NS, KS, Epi, ot - 1, ks>::run(epi, acc[(ot - 1) & 1]);
+    if constexpr (ot == OT - 1 && ks == KS - 1) EpiPieces<C::NS, KS, Epi, ot, -1>::run(epi, acc[ot & 1]);
     if constexpr (S::sync_after(J)) { rg.blk = blk0 + J / kBlkFrags; rg.sync_point(); }
-    if constexpr (J + 1 < S::NF) PartStep<KS, OT, BSel, Epi, BIAS, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
+    if constexpr (J + 1 < S::NF) PartStep<C, KS, OT, BSel, Epi, BIAS, J + 1>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   }
 };
 
@@ -219,19 +234,19 @@ __device__ __forceinline__ void prime_frags_bf(bf16x8 (&fr)[kPD + 1], uint32_t a
 }
 // Runs one part that starts at block rg.blk (block-aligned) and leaves rg.blk at the next part's first block.
 // bias_addr: LDS byte address of the part's accumulator-init vector + h*16.
-template <int KS, int OT, bool BIAS = true, class BSel, class Epi>
-__device__ __forceinline__ void run_part(BfRing& rg, uint32_t bias_addr, const BSel& bsel, Epi& epi) {
+template <int KS, int OT, bool BIAS = true, class C, class BSel, class Epi>
+__device__ __forceinline__ void run_part(BfRingT<C>& rg, uint32_t bias_addr, const BSel& bsel, Epi& epi) {
   static_assert(!BIAS || KS >= 2 || OT == 1, "the init rows of the next tile are requested at k-step 1");
   static_assert(OT == 1 || piece_offset<KS, Epi::kPieces>(Epi::kPieces - 1) < KS, "epilogue pieces must fit into the next tile");
   using S = PartSched<KS, OT, BIAS>;
   const int blk0 = rg.blk;
   bf16x8 fr[kPD + 1];
   BiasBuf bias;
-  f32x16 acc[2][kNS];
+  f32x16 acc[2][C::NS];
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (BIAS) bias_read<0>(bias, bias_addr);
   prime_frags_bf<S::NF, 0>(fr, rg.slot_addr(blk0));
-  PartStep<KS, OT, BSel, Epi, BIAS, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
+  PartStep<C, KS, OT, BSel, Epi, BIAS, 0>::run(rg, blk0, bias_addr, fr, bias, acc, bsel, epi);
   wait_lgkm_n<0>();
   __builtin_amdgcn_sched_barrier(0);
   rg.blk = blk0 + (S::NF + kBlkFrags - 1) / kBlkFrags;

@@ -4,42 +4,53 @@
 // accumulation (BASELINE config 5; parity bar: renders within 1e-2 abs of the fp32 path).  Positions, the
 // encoding's sin/cos, biases, the per-ray view-direction branch and all accumulators are fp32; weights and
 // the activations fed to the next layer are rounded to bf16 (RNE).  Machinery: bf16_common.hip.h.
-// One wave = 32 samples x all features; workgroup = 8 waves = 256 samples, persistent (one per CU).
+// One wave = 32 samples x all features, workgroup = 8 waves (two per SIMD) = 256 samples, persistent (one per CU).  The
+// kernel is templated on the sample tiles per wave (bf16_common.hip.h: BfCfg); NH_BF_INFER_NS below says why inference
+// stays at one.
 // Stream layout (api.hip: build_bf16_stream): layer 0 | layers 1..D-1 (skip layers carry 4 extra k-steps for
 // the encoding) | head: HT colour-hidden tiles + one tile whose row 0 is the density row | (mode 1) colour
 // output layer, 1 tile over K = 32 HT.  The sigma-only stream (coarse pass of inference) ends with the density
 // tile alone.
 #include "bf16_common.hip.h"
 #include <algorithm>
+// Sample tiles per wave of the INFERENCE kernel.  2 (four waves, one per SIMD, every LDS fragment feeding two MFMAs) was
+// built and measured in round 3: it renders the same pixels (tests/test_gpu_bf16.py green) but no faster -- with the skip
+// layer's encoding live the 512-register file overflows (158-227 spilled registers: 1.04-1.24 PF), and a build without
+// the skip layer, where it fits, runs at the one-tile kernel's rate (1.418 against 1.440 PF; profiles/r3_bf16_ns2_*): the
+// LDS read port (256 B/clk/CU for ds_read_b128, half used) was never the limit, the kernel is clock/power-limited.
+#ifndef NH_BF_INFER_NS
+#define NH_BF_INFER_NS 1
+#endif
 #include "launchers.h"
 
 namespace nh {
 
-template <int WT>
-struct ActRegs { bf16x8 v[kNS][WT][2]; };
+template <int NS, int WT>
+struct ActRegs { bf16x8 v[NS][WT][2]; };
 
-template <int WT>
+template <int NS, int WT>
 struct SelAct {   // k-steps 0 .. 2WT-1: previous layer; 2WT .. 2WT+3: encoding (skip layers)
-  const ActRegs<WT>& a;
-  const ActRegs<2>* e;
+  const ActRegs<NS, WT>& a;
+  const ActRegs<NS, 2>* e;
   template <int KS_IDX> __device__ __forceinline__ const bf16x8& b(int n) const {
     if constexpr (KS_IDX < 2 * WT) return a.v[n][KS_IDX / 2][KS_IDX % 2];
     else return e->v[n][(KS_IDX - 2 * WT) / 2][KS_IDX % 2];
   }
 };
+template <int NS>
 struct SelEnc {
-  const ActRegs<2>& e;
+  const ActRegs<NS, 2>& e;
   template <int KS_IDX> __device__ __forceinline__ const bf16x8& b(int n) const { return e.v[n][KS_IDX / 2][KS_IDX % 2]; }
 };
-template <int HT>
+template <int NS, int HT>
 struct SelHid {
-  const ActRegs<HT>& a;
+  const ActRegs<NS, HT>& a;
   template <int KS_IDX> __device__ __forceinline__ const bf16x8& b(int n) const { return a.v[n][KS_IDX / 2][KS_IDX % 2]; }
 };
-template <int H>
-__device__ __forceinline__ void encode_half(ActRegs<2>& enc, const float (&pos)[kNS][3], int E) {
+template <int H, int NS>
+__device__ __forceinline__ void encode_half(ActRegs<NS, 2>& enc, const float (&pos)[NS][3], int E) {
 #pragma unroll
-  for (int n = 0; n < kNS; ++n)
+  for (int n = 0; n < NS; ++n)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -55,16 +66,17 @@ __device__ __forceinline__ void store_frag(char* tile_lane, int kt, int s, const
   // streams out of the XCD's L2
   __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(tile_lane + (kt * 2 + s) * 1024));
 }
-template <int WT, bool TRAIN>
+template <class C, int WT, bool TRAIN>
 struct EpiTrunk {   // relu + bf16 -> B operand of the next layer (TRAIN: also into the activation store)
-  ActRegs<WT>& out;
+  static constexpr int kNS = C::NS;
+  ActRegs<kNS, WT>& out;
   char* dst;        // TRAIN: this wave's tile of the layer's activation buffer + lane*16
   u32x4* bits_dst;  // TRAIN: this lane's 16 B of the layer's ReLU' bits
-  BfRing& rg;
+  BfRingT<C>& rg;
   u32x4 bits;
   static constexpr int kPieces = 2 * kNS;   // (sample tile, k-step half)
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
-    static_assert(kNS == 1, "store addressing assumes one sample tile per wave");
+    static_assert(!TRAIN || kNS == 1, "store addressing assumes one sample tile per wave");
     out.v[P / 2][OT_IDX][P % 2] = relu_pack_half<P % 2>(acc[P / 2]);
     if constexpr (TRAIN) {
       store_frag(dst, OT_IDX, P % 2, out.v[P / 2][OT_IDX][P % 2]);
@@ -75,6 +87,7 @@ struct EpiTrunk {   // relu + bf16 -> B operand of the next layer (TRAIN: also i
   }
 };
 
+template <int kNS>
 struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.scala:39-40)
   float* sigma; const int* m; const bool* valid; int h;
   static constexpr int kPieces = 1;
@@ -84,10 +97,10 @@ struct EpiSigma {   // one tile whose row 0 is the density row (nerfCoreBlock.sc
       if (valid[n] && h == 0) sigma[m[n]] = acc[n][0];
   }
 };
-template <int HT, int MODE, bool TRAIN>
+template <int kNS, int HT, int MODE, bool TRAIN>
 struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
   char* hc_dst;     // TRAIN, mode 1: this wave's tile of the hc buffer + lane*16
-  ActRegs<HT>& hid; float (&c)[kNS][3];
+  ActRegs<kNS, HT>& hid; float (&c)[kNS][3];
   const float* dirfeat; const int* ray; const int* m; const bool* valid; float* sigma; int h;
   static constexpr int kPieces = 1;
   template <int OT_IDX, int P> __device__ __forceinline__ void piece(f32x16 (&acc)[kNS]) {
@@ -132,6 +145,7 @@ struct EpiHead {    // tiles 0..HT-1: first head matrix; tile HT: density row
     }
   }
 };
+template <int kNS>
 struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
   float (&c)[kNS][3]; int h;
   static constexpr int kPieces = 1;
@@ -142,8 +156,8 @@ struct EpiColour {   // colour output layer (rows 0..2 of its single tile)
   }
 };
 
-template <int WT, int MODE, bool TRAIN>
-__global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net, const char* __restrict__ stream,
+template <int WT, int MODE, bool TRAIN, int NS>
+__global__ __launch_bounds__(64 * (NS == 1 ? 8 : 4)) void mlp_fwd_bf16_kernel(NetArgs net, const char* __restrict__ stream,
                                                               const float* __restrict__ bvec,
                                                               const float* __restrict__ rays_o,
                                                               const float* __restrict__ rays_d,
@@ -151,6 +165,9 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
                                                               const float* __restrict__ dirfeat, int64_t M, int S,
                                                               float* __restrict__ sigma, float* __restrict__ craw,
                                                               int want_rgb, int nblk, int ntiles, BfStore st) {
+  using C = BfCfg<NS, (NS == 1 ? 8 : 4)>;
+  constexpr int kNS = NS, kBfWaves = C::WAVES, kBfTile = C::TILE;
+  static_assert(!TRAIN || NS == 1, "the activation store is written one sample tile per wave");
   constexpr int R = 32 * WT;
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   extern __shared__ __attribute__((aligned(1024))) float smem[];   // ring (kRing x 32 KiB) | vectors
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
   const int D = net.D;
   const int nvec = D * R + (HT + 1) * 32 + 32;
 
-  BfRing rg;
+  BfRingT<C> rg;
   rg.stream = stream;
   rg.ring = smem;
   rg.ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem + (uint32_t)lane * 16u;
@@ -193,11 +210,11 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
   }
   // The encoding (2 k-tiles of B operand) is recomputed where it is needed (layer 0, skip layers) instead of
   // being kept live through the whole trunk: 3 VALU per value with the hardware sin/cos, and 32 registers less.
-  auto encode = [&](ActRegs<2>& enc) {
+  auto encode = [&](ActRegs<kNS, 2>& enc) {
     // the feature a register element holds depends on the lane half only through "+4h": one pass per half with
     // every index a compile-time constant (3 VALU per value), instead of per-lane index arithmetic
-    if (h == 0) encode_half<0>(enc, pos, net.E);
-    else encode_half<1>(enc, pos, net.E);
+    if (h == 0) encode_half<0, kNS>(enc, pos, net.E);
+    else encode_half<1, kNS>(enc, pos, net.E);
   };
   // TRAIN: this wave's sample tile in the activation store
   const int64_t tix = (int64_t)tile * kBfWaves + wave;
@@ -207,32 +224,32 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
   auto bits_lane = [&](int l) {   // this lane's 16 B of layer l's ReLU' bits (BfStore::relu)
     return reinterpret_cast<u32x4*>(st.relu + (int64_t)l * st.Mpad * 8) + tix * 64 + lane;
   };
-  ActRegs<WT> act, nxt;
+  ActRegs<kNS, WT> act, nxt;
   {
-    ActRegs<2> enc;
+    ActRegs<kNS, 2> enc;
     encode(enc);
     if constexpr (TRAIN) {
       char* e = tile_lane(st.enc, 2);
       store_frag(e, 0, 0, enc.v[0][0][0]); store_frag(e, 0, 1, enc.v[0][0][1]);
       store_frag(e, 1, 0, enc.v[0][1][0]); store_frag(e, 1, 1, enc.v[0][1][1]);
     }
-    EpiTrunk<WT, TRAIN> epi{act, TRAIN ? tile_lane(st.act, WT) : nullptr, TRAIN ? bits_lane(0) : nullptr, rg, {0u, 0u, 0u, 0u}};
-    run_part<4, WT>(rg, vec_addr, SelEnc{enc}, epi);   // layer 0
+    EpiTrunk<C, WT, TRAIN> epi{act, TRAIN ? tile_lane(st.act, WT) : nullptr, TRAIN ? bits_lane(0) : nullptr, rg, {0u, 0u, 0u, 0u}};
+    run_part<4, WT>(rg, vec_addr, SelEnc<kNS>{enc}, epi);   // layer 0
   }
   // layers 1..D-1, two per trip (act -> nxt -> act) so the activations never have to be copied
-  auto layer = [&](int l, const ActRegs<WT>& in, ActRegs<WT>& out) {
-    EpiTrunk<WT, TRAIN> epi{out, TRAIN ? tile_lane(st.act + (int64_t)l * R * st.Mpad, WT) : nullptr, TRAIN ? bits_lane(l) : nullptr, rg, {0u, 0u, 0u, 0u}};
+  auto layer = [&](int l, const ActRegs<kNS, WT>& in, ActRegs<kNS, WT>& out) {
+    EpiTrunk<C, WT, TRAIN> epi{out, TRAIN ? tile_lane(st.act + (int64_t)l * R * st.Mpad, WT) : nullptr, TRAIN ? bits_lane(l) : nullptr, rg, {0u, 0u, 0u, 0u}};
     const uint32_t baddr = vec_addr + (uint32_t)(l * R) * 4u;
     if ((net.skip_mask >> (l - 1)) & 1u) {
       // recompute the encoding HERE: made opaque so that it is not hoisted out of the layer loop (it would then be
       // live -- and spilled -- through the whole trunk)
 #pragma unroll
       for (int n = 0; n < kNS; ++n) asm volatile("" : "+v"(pos[n][0]), "+v"(pos[n][1]), "+v"(pos[n][2]));
-      ActRegs<2> enc;
+      ActRegs<kNS, 2> enc;
       encode(enc);
-      run_part<2 * WT + 4, WT>(rg, baddr, SelAct<WT>{in, &enc}, epi);
+      run_part<2 * WT + 4, WT>(rg, baddr, SelAct<kNS, WT>{in, &enc}, epi);
     } else {
-      run_part<2 * WT, WT>(rg, baddr, SelAct<WT>{in, nullptr}, epi);
+      run_part<2 * WT, WT>(rg, baddr, SelAct<kNS, WT>{in, nullptr}, epi);
     }
   };
   int l = 1;
@@ -248,23 +265,23 @@ __global__ __launch_bounds__(64 * kBfWaves) void mlp_fwd_bf16_kernel(NetArgs net
   const uint32_t haddr = vec_addr + (uint32_t)(D * R) * 4u;
   if (!want_rgb) {
     // sigma-only stream: one tile, row 0 = density row (nerfCoreBlock.scala:39-40)
-    EpiSigma epi{sigma, m, valid, h};
-    run_part<2 * WT, 1>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<WT>{act, nullptr}, epi);
+    EpiSigma<kNS> epi{sigma, m, valid, h};
+    run_part<2 * WT, 1>(rg, haddr + (uint32_t)(HT * 32) * 4u, SelAct<kNS, WT>{act, nullptr}, epi);
     continue;
   }
 
   // head: HT colour tiles, then the density tile
-  ActRegs<HT> hid;
+  ActRegs<kNS, HT> hid;
   float c[kNS][3];
 #pragma unroll
   for (int n = 0; n < kNS; ++n) c[n][0] = c[n][1] = c[n][2] = 0.f;
-  EpiHead<HT, MODE, TRAIN> epih{(TRAIN && MODE == 1) ? tile_lane(st.hc, HT) : nullptr, hid, c, dirfeat, ray, m, valid, sigma, h};
-  run_part<2 * WT, HT + 1>(rg, haddr, SelAct<WT>{act, nullptr}, epih);
+  EpiHead<kNS, HT, MODE, TRAIN> epih{(TRAIN && MODE == 1) ? tile_lane(st.hc, HT) : nullptr, hid, c, dirfeat, ray, m, valid, sigma, h};
+  run_part<2 * WT, HT + 1>(rg, haddr, SelAct<kNS, WT>{act, nullptr}, epih);
 
   if constexpr (MODE == 1) {
     // colour output layer: Linear(3) over the H2 hidden features, as one MFMA tile (rows 0..2)
-    EpiColour epic{c, h};
-    run_part<2 * HT, 1>(rg, haddr + (uint32_t)((HT + 1) * 32) * 4u, SelHid<HT>{hid}, epic);
+    EpiColour<kNS> epic{c, h};
+    run_part<2 * HT, 1>(rg, haddr + (uint32_t)((HT + 1) * 32) * 4u, SelHid<kNS, HT>{hid}, epic);
   } else if constexpr (MODE == 2) {
 #pragma unroll
     for (int n = 0; n < kNS; ++n) {
@@ -285,9 +302,11 @@ static hipError_t launch_one(const BfStore& st, const NetArgs& net, const void* 
   constexpr int HT = MODE == 1 ? (WT >= 2 ? WT / 2 : 1) : 1;
   const size_t lds = (size_t)kRing * kBlkBytes + ((size_t)net.D * 32 * WT + (HT + 1) * 32 + 32) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  const int ntiles = (int)((M + kBfTile - 1) / kBfTile);
-  const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * kBfWaves);   // one persistent workgroup per CU
-  hipLaunchKernelGGL((mlp_fwd_bf16_kernel<WT, MODE, TRAIN>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
+  constexpr int NS = TRAIN ? 1 : NH_BF_INFER_NS;   // inference: sample tiles per wave (2: four waves, BfCfg<2, 4>)
+  using C = BfCfg<NS, (NS == 1 ? 8 : 4)>;
+  const int ntiles = (int)((M + C::TILE - 1) / C::TILE);
+  const dim3 grid((unsigned)std::min(ntiles, n_cu)), block(64 * C::WAVES);   // one persistent workgroup per CU
+  hipLaunchKernelGGL((mlp_fwd_bf16_kernel<WT, MODE, TRAIN, NS>), grid, block, lds, stream, net, (const char*)stream_w, bvec, rays_o,
                      rays_d, z, dirfeat, M, S, sigma, craw, want_rgb, nblk, ntiles, st);
   return hipGetLastError();
 }
@@ -306,9 +325,9 @@ static hipError_t launch_mode(const BfStore* st, const NetArgs& net, const void*
 // once per device, with that device current (nerfhip_create): every instantiation may use the whole 160-KiB LDS
 template <int WT, int MODE>
 static hipError_t prepare_fwd_one() {
-  hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return hipFuncSetAttribute((const void*)mlp_fwd_bf16_kernel<WT, MODE, false, NH_BF_INFER_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 hipError_t prepare_mlp_fwd_bf16(int W, int mode) {
   switch ((W / 32) * 4 + mode) {
