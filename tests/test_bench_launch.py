@@ -45,3 +45,26 @@ def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-launch"], env=_env(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "n_gpus" not in r.stdout
+
+
+def test_roofline_traffic_is_null_for_a_library_built_from_other_sources(tmp_path, monkeypatch):
+    """bench.py quotes counter traffic only from a PMC summary whose recorded nerfhip_version() (release
+    + hash of the kernel sources) equals the loaded library's; any other summary is stale and yields null with the reason."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from nerf_amd import _lib
+    mine = _lib.load().nerfhip_version().decode()
+    assert " src " in mine and len(mine.rsplit(" ", 1)[1]) == 12          # a 12-hex-digit source hash rides in the version
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    hdr = "kernel,dispatches,total_ms,FETCH_SIZE\n"
+    (prof / "rX_f32_pmc_fetchsize.csv").write_text(hdr + '"void nh::mlp_fwd_f32_kernel<8, true>",6,1.0,3000\n')
+    (prof / "rX_f32_pmc_writesize.csv").write_text(hdr.replace("FETCH", "WRITE") + '"void nh::mlp_fwd_f32_kernel<8, true>",6,1.0,6000\n')
+    (prof / "rX_f32_pmc_meta.json").write_text(json.dumps({"nerfhip_version": "nerfhip 0.3 (other) src 000000000000"}))
+    r = bench.pmc_traffic("mlp_fwd", "f32")
+    assert r["traffic"] is None and "other sources" in r["traffic_note"]
+    (prof / "rX_f32_pmc_meta.json").write_text(json.dumps({"nerfhip_version": mine}))
+    r = bench.pmc_traffic("mlp_fwd", "f32")
+    assert r["traffic"] == round((2.0 * 3000 + 6000) * 1024 / 3.0)          # FETCH_SIZE doubled (gfx950), KB, 3 profiled steps
+    assert bench.pmc_traffic("mlp_wgrad", "bf16")["traffic"] is None       # no summary of that dtype at all
