@@ -2,12 +2,13 @@
  * a maintainer would put under the reference's Scala entry points (nerfBlock.scala:146-157 forwardInternal,
  * runNerf.scala:100-106 train step, :181-204 renderToImage).  No Python, no torch, no C++:
  * it proves the header is valid C, that the structs have the layout the other bindings assume, and that the call
- * sequence create -> set_params -> render -> render_u8 -> train_step -> get_params -> destroy works from C.
+ * sequence create -> set_params -> render -> render_u8 -> render_pose(_rows)_u8 -> train_step -> get_params -> destroy
+ * works from C.
  *
  *   c_abi_driver layout            prints sizeof / offsetof of every struct of the ABI (no GPU needed)
  *   c_abi_driver run <dir>         reads <dir>/config.bin (raw struct nerfhip_config), params.bin, rays_o.bin,
  *                                  rays_d.bin, bounds.bin, label.bin (raw little-endian fp32, [n][.]); writes
- *                                  rgb.bin, u8.bin, depth.bin, loss.bin, params_after.bin, grads.bin
+ *                                  rgb.bin, u8.bin, depth.bin, pose.bin, loss.bin, params_after.bin, grads.bin
  * Built by __graft_entry__.build() with gcc -std=c11 -Wall -Wextra -pedantic. */
 #include <stddef.h>
 #include <stdint.h>
@@ -102,6 +103,24 @@ static int run(const char* dir) {
   dump(dir, "rgb.bin", rgb, (size_t)n * 3 * sizeof(float));
   dump(dir, "depth.bin", depth, (size_t)n * sizeof(float));
   dump(dir, "u8.bin", u8, (size_t)n * 3);
+
+  /* renderToImage from a pose (runNerf.scala:181-204), whole and as three row blocks of unequal height -- the shape of a
+   * frame sharded over GPUs (BASELINE configs[2]); stacked, the blocks must be the whole frame byte for byte */
+  {
+    enum { PH = 26, PW = 10 };
+    const float c2w[12] = {1.f, 0.f, 0.f, 0.2f, 0.f, 0.6f, -0.8f, -3.2f, 0.f, 0.8f, 0.6f, 2.4f};
+    const float focal = 22.0f;
+    uint8_t whole[PH * PW * 3], rows[PH * PW * 3];
+    const int cut[4] = {0, 9, 18, PH};
+    CHK(h, nerfhip_render_pose_u8(h, PH, PW, focal, c2w, 2.0f, 6.0f, 0, whole));
+    for (int k = 0; k < 3; ++k)
+      CHK(h, nerfhip_render_pose_rows_u8(h, PH, PW, focal, c2w, 2.0f, 6.0f, 0, cut[k], cut[k + 1], rows + (size_t)cut[k] * PW * 3));
+    if (memcmp(whole, rows, sizeof whole) != 0) { fprintf(stderr, "row blocks differ from the whole frame\n"); return 1; }
+    CHK(h, nerfhip_render_pose_rows_u8(h, PH, PW, focal, c2w, 2.0f, 6.0f, 0, 7, 7, NULL));   /* a rank without rows */
+    if (nerfhip_render_pose_rows_u8(h, PH, PW, focal, c2w, 2.0f, 6.0f, 0, 3, PH + 1, rows) != NERFHIP_E_INVALID) {
+      fprintf(stderr, "rows past the image were not refused\n"); return 1; }
+    dump(dir, "pose.bin", whole, sizeof whole);
+  }
 
   /* one training iteration (runNerf.scala:94-106), gradients read back before the optimizer consumes them */
   float loss[2] = {0.f, 0.f};

@@ -41,6 +41,9 @@ def test_c_driver_equals_ctypes_path(tmp_path, name, dtype):
     np.testing.assert_array_equal(rd_("rgb").reshape(n, 3), fine)
     np.testing.assert_array_equal(rd_("depth"), dbg["depth"])
     np.testing.assert_array_equal(rd_("u8", np.uint8).reshape(n, 3), blk.render_u8(ro, rd, b, rd))
+    # the frame the C program rendered from its pose (whole == three row blocks was checked there, in C)
+    c2w = np.array([[1, 0, 0, 0.2], [0, 0.6, -0.8, -3.2], [0, 0.8, 0.6, 2.4]], np.float32)
+    np.testing.assert_array_equal(rd_("pose", np.uint8).reshape(26, 10, 3), blk.render_pose(26, 10, 22.0, c2w, 2.0, 6.0, False))
     lf, lc = blk.train_backward(ro, rd, b, rd, label)
     g = blk.get_grads()
     blk.optimizer_step()
