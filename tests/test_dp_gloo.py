@@ -76,6 +76,17 @@ def _worker(rank, world, port, reduce, out):
     r0, r1 = row_block(Himg, rank, world)
     rows = torch.arange(r0 * Wimg, r1 * Wimg, dtype=torch.float32).reshape(r1 - r0, Wimg, 1).repeat(1, 1, 3)
     img = dp.gather_rows(rows, Himg)
+    # bench.py's sharded-frame leg (BASELINE configs[2]) with a stand-in block: uint8 row blocks of unequal height from
+    # "the pose", stacked in rank order through the same gather
+    from nerf_amd.dp import render_sharded_frame
+
+    class RowsOnly:
+        def render_pose_rows(self, Hh, Ww, focal, c2w, near, far, ndc, a, z):
+            return (np.arange(a * Ww * 3, z * Ww * 3) % 251).astype(np.uint8).reshape(z - a, Ww, 3)
+    frame = render_sharded_frame(RowsOnly(), Himg, Wimg, 1.0, None, 2.0, 6.0, False, rank, world,
+                                 lambda r: dp.gather_rows(torch.from_numpy(r), Himg).numpy())
+    assert frame.dtype == np.uint8 and frame.shape == (Himg, Wimg, 3)
+    np.testing.assert_array_equal(frame.ravel(), (np.arange(Himg * Wimg * 3) % 251).astype(np.uint8))
     out[rank] = (eng.p.copy(), losses, img.numpy())
     dist.destroy_process_group()
 
