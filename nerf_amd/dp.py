@@ -147,6 +147,16 @@ class DataParallel:
         st = self._bcast(np.array([step], np.int64), src)
         block.set_opt_state(self._bcast(m, src), self._bcast(v, src), int(st[0]))
 
+    def gather_rows_host(self, rows_u8, H, device=None):
+        """`gather_rows` for a numpy row block (what nerfhip_render_pose_rows_u8 hands back): staged through a device tensor
+        when the group's backend only carries those (RCCL), through a host tensor otherwise (gloo); numpy [H][W][3] out"""
+        if self.world == 1:
+            return rows_u8
+        t = torch.from_numpy(rows_u8)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.to(device if device is not None else "cuda")
+        return self.gather_rows(t, H).cpu().numpy()
+
     def gather_rows(self, local_rows, H):
         """all-gather row blocks of a rendered image (uint8 or float tensor [rows, W, 3]) on every rank"""
         if self.world == 1:

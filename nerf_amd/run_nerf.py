@@ -19,7 +19,8 @@ weights are saved as .npz with the Adam state (NerfBlock.save_checkpoint) instea
 Several devices (`config.device` with more than one entry, `next.split(devices)`, :95): one process per GPU, each
 calls train(..., dp=DataParallel.for_block(block), seed=<same on every rank>) after dp.shared_stream(block); every
 rank draws the same permutation, takes its slice of each batch (split_batch), the gradients are all-reduced once per
-step (nerf_amd/dp.py), rank 0 alone writes logs, images and weights.
+step (nerf_amd/dp.py), rank 0 alone writes logs, images and weights; the logged images and video frames are rendered by
+ALL ranks, a contiguous block of rows each (render_to_image with dp: BASELINE configs[2], runNerf.scala:187-199).
 """
 import os
 from dataclasses import dataclass
@@ -57,9 +58,18 @@ def get_data_set(block, cfg: NerfConfig, run: RunConfig):
     raise ValueError(f"Dataset type {run.dataSetType!r} not supported")          # getDataSet.scala:69
 
 
-def render_to_image(block, ds, poses):
-    """runNerf.renderToImage for the images of `poses` ([P][3][4]) of data set `ds` -> uint8 [P][H][W][3]."""
-    return np.stack([block.render_pose(ds.H, ds.W, ds.focal, p, ds.near, ds.far, ds.ndc) for p in poses], 0)
+def render_to_image(block, ds, poses, dp=None):
+    """runNerf.renderToImage for the images of `poses` ([P][3][4]) of data set `ds` -> uint8 [P][H][W][3].
+    With a multi-rank `dp` this is a COLLECTIVE: every rank renders its contiguous row block of every frame from the pose
+    (runNerf.scala:187-199 evaluates the rows one by one and stacks them; SURVEY 8e: row blocks per GPU, no collective on
+    the data path) and the blocks are gathered in rank order -- the frame every rank returns equals the single-GPU one
+    bit for bit, in 1/world of the time."""
+    if dp is None or dp.world == 1:
+        return np.stack([block.render_pose(ds.H, ds.W, ds.focal, p, ds.near, ds.far, ds.ndc) for p in poses], 0)
+    from .dp import render_sharded_frame
+    dev = f"cuda:{block.config.device}"
+    return np.stack([render_sharded_frame(block, ds.H, ds.W, ds.focal, p, ds.near, ds.far, ds.ndc, dp.rank, dp.world,
+                                          lambda rows: dp.gather_rows_host(rows, ds.H, dev)) for p in poses], 0)
 
 
 def _save_png(path, u8):
@@ -163,10 +173,12 @@ def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None, dp=N
                     say(f"{idx} iterators train: loss is {mean}.")
                     out["train_loss"].append((idx, mean))
                     loss_sum = np.float32(0)
-                if rank == 0 and idx % run.iImage == 0 and len(val_poses):
+                if idx % run.iImage == 0 and len(val_poses):          # every rank: the frame's rows are shared out
                     who = (idx // run.iImage - 1) % len(val_poses)
                     say(f"{idx} iterators: log image.")
-                    _save_png(os.path.join(dirs["imageLogs"], f"{idx}.png"), render_to_image(block, ds, val_poses[who:who + 1])[0])
+                    img = render_to_image(block, ds, val_poses[who:who + 1], dp)[0]
+                    if rank == 0:
+                        _save_png(os.path.join(dirs["imageLogs"], f"{idx}.png"), img)
                     say("Log over.")
                 if rank == 0 and idx % run.iWeight == 0:
                     say(f"{idx} iterators: save weight.")
@@ -175,12 +187,15 @@ def train(cfg: NerfConfig, run: RunConfig, block=None, log=None, seed=None, dp=N
                 if rank == 0 and idx % run.iTestSet == 0:
                     say(f"{idx} iterators: start to test.")
                     out["test_loss"].append((idx, eval_test_set(block, ds, cfg.batchNum, run.iPrint, say)))
-                if rank == 0 and idx % run.iVideo == 0:
+                if idx % run.iVideo == 0:                              # every rank, as the image log
                     say(f"{idx} iterators: log video.")
                     path = os.path.join(dirs["videoLogs"], str(idx))
-                    os.makedirs(path, exist_ok=True)
+                    if rank == 0:
+                        os.makedirs(path, exist_ok=True)
                     for i, p in enumerate(ds.render_poses):
-                        _save_png(os.path.join(path, f"{i}.png"), render_to_image(block, ds, p[None])[0])
+                        img = render_to_image(block, ds, p[None], dp)[0]
+                        if rank == 0:
+                            _save_png(os.path.join(path, f"{i}.png"), img)
                     say("Log over.")
                 if idx % run.NIter == 0:
                     say(f"{idx} iterators: train over.")

@@ -26,7 +26,7 @@ def _cfg():
 def _run(scene, logdir):
     from nerf_amd import run_nerf as R
     return R.RunConfig(dataSetType="blender", halfRes=False, testSkip=2, dataDir=scene, logDir=logdir, iPrint=1,
-                       iImage=100, iWeight=100, iTestSet=100, iVideo=100, NIter=6)
+                       iImage=3, iWeight=100, iTestSet=100, iVideo=100, NIter=6)
 
 
 def _worker(rank, world, port, scene, outdir):
@@ -46,8 +46,13 @@ def _worker(rank, world, port, scene, outdir):
         shared_stream(blk)
         dp = DataParallel.for_block(blk, all_reduce=host_staged_all_reduce())
         res = R.train(cfg, _run(scene, os.path.join(outdir, "log_dp")), block=blk, seed=3, dp=dp)
+        # the image logged at step 6 was rendered by BOTH ranks, half of the rows each (run_nerf.render_to_image with dp);
+        # replicas are bit-identical, so this rank's own whole-frame render of the same pose must equal it exactly
+        ds = res["data"]
+        who = (6 // 3 - 1) % len(ds.split_poses["val"])
+        whole = blk.render_pose(ds.H, ds.W, ds.focal, ds.split_poses["val"][who], ds.near, ds.far, ds.ndc)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), params=blk.get_params(),
-                 losses=np.array([v for _, v in res["train_loss"]], np.float64))
+                 losses=np.array([v for _, v in res["train_loss"]], np.float64), whole=whole)
         blk.close()
     finally:
         dist.destroy_process_group()
@@ -78,6 +83,12 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path):
     # rank 0 alone wrote the log
     log = (tmp_path / "log_dp" / "log.txt").read_text().splitlines()
     assert log[0] == "Train start." and log[-1] == "Train over." and sum("iterators train" in l for l in log) == 6
+    # ... and the images, whose rows the two ranks rendered half each: equal to either rank's own whole frame
+    from PIL import Image
+    assert sum("log image" in l for l in log) == 2
+    png = np.asarray(Image.open(tmp_path / "log_dp" / "imageLogs" / "6.png"))
+    np.testing.assert_array_equal(png, r0["whole"])
+    np.testing.assert_array_equal(png, r1["whole"])
     # one process, whole batches, same permutations: the same trajectory up to summation order
     cfg = _cfg()
     blk = NerfBlock(cfg)
