@@ -3,7 +3,10 @@
 sizes drawn at random, rendered and differentiated on the GPU and by the oracle with the same explicit random tensors.
 The hand-picked cases elsewhere cover the shapes someone thought of; this covers the combinations nobody did.
 Bars: sampler outputs bit-exact on identical inputs, render 2e-4 abs and gradients 1e-3 (whole) / 5e-3 (per tensor) with
-the oracle evaluated at the device's fine depths (tests/test_gpu_train.py: test_gradients_full explains why)."""
+the oracle evaluated at the device's fine depths (tests/test_gpu_train.py: test_gradients_full explains why).
+The seeds kept here are green; of 420 explored (scripts/fuzz_explore.py) one, 355, puts a pre-activation within fp32 rounding of
+zero (-4.2e-8 against a typical 0.66), where device and oracle legitimately take different sides of the ReLU: one row of one
+matrix and the layers below it move by 0.5-0.9 % of their norms (scripts/fuzz_one.py prints where the error sits)."""
 import numpy as np
 import pytest
 
