@@ -96,3 +96,30 @@ def test_config2_pose_rows_of_a_faked_world_stack_to_the_whole_frame(dtype, worl
             blk.render_pose_rows(Himg, Wimg, focal, pose, 2.0, 6.0, False, 10, Himg + 1)
     finally:
         blk.close()
+
+
+def test_ndc_pose_rows_stack_to_the_whole_frame_and_equal_explicit_rays():
+    """The same sharding for a forward-facing scene (BASELINE configs[4]'s rays: ndc = true, llff.scala:96-132): the row
+    blocks of a world that does not divide the rows equal the single-call frame, which equals the frame rendered from the
+    rays the device generator writes out (pixel (j, i) of a block is pixel (row0 + j, i) of the frame)."""
+    c = dict(H.CONFIGS["full"], NImportance=32)
+    Himg, Wimg, world = 37, 20, 3
+    focal = 0.9 * Wimg
+    pose = np.array([[1, 0, 0, 0.05], [0, 1, 0, 0.02], [0, 0, 1, 0.1]], np.float32)
+    blk = G.make_block(c, max_rays=256)
+    blk.init_params(6)
+    try:
+        whole = blk.render_pose(Himg, Wimg, focal, pose, 0.0, 1.0, True)
+        parts = [render_sharded_frame(blk, Himg, Wimg, focal, pose, 0.0, 1.0, True, rank, world) for rank in range(world)]
+        np.testing.assert_array_equal(np.concatenate(parts, 0), whole)
+        n = Himg * Wimg
+        ro, rd, bd = G.empty(n, 3), G.empty(n, 3), G.empty(n, 2)
+        blk.k_gen_rays(Himg, Wimg, focal, pose, 0.0, 1.0, True, ro, rd, bd)
+        blk.synchronize()
+        ro, rd, bd = ro.cpu().numpy(), rd.cpu().numpy(), bd.cpu().numpy()
+        o_ro, o_rd, o_bd = Oracle(c).gen_rays(Himg, Wimg, focal, pose, 0.0, 1.0, True)
+        np.testing.assert_array_equal(ro, o_ro); np.testing.assert_array_equal(rd, o_rd); np.testing.assert_array_equal(bd, o_bd)
+        np.testing.assert_array_equal(blk.render_u8(ro, rd, bd, rd).reshape(Himg, Wimg, 3), whole)
+        assert whole.std() > 0                                                    # a picture, not a constant
+    finally:
+        blk.close()
