@@ -39,3 +39,11 @@ else:
     span = int(sel[-1]["End_Timestamp"]) - int(rows[first - 1]["End_Timestamp"])
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel)
     print(f"launches/step {len(sel) / steps:.1f}  span {span / steps / 1e6:.4f} ms/step  kernels {busy / steps / 1e6:.4f}  gaps {(span - busy) / steps / 1e6:.4f}")
+    if len(sys.argv) > 4 and sys.argv[4] == "by":     # per-kernel share of a step (us per step, launches per step)
+        by = {}
+        for r in sel:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
+            t, n = by.get(k, (0, 0))
+            by[k] = (t + int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), n + 1)
+        for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0]):
+            print(f"  {k:60s} {t / steps / 1e3:9.2f} us/step  {n / steps:5.1f} launches")
