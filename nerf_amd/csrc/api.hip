@@ -48,6 +48,12 @@ struct Net {
   FragDesc* d_bf_sigma_desc = nullptr;
   void* d_bf_full = nullptr;
   void* d_bf_sigma = nullptr;
+  // the same two streams in the fragment order of the 16x16x32 inference kernel (mlp_fwd_bf16_t16.hip)
+  std::vector<FragDesc> bf_full16, bf_sigma16;
+  FragDesc* d_bf_full16_desc = nullptr;
+  FragDesc* d_bf_sigma16_desc = nullptr;
+  void* d_bf_full16 = nullptr;
+  void* d_bf_sigma16 = nullptr;
   float* d_bvec = nullptr;
   std::vector<FragDesc> bf_bwd;                 // backward stream (transposed matrices)
   FragDesc* d_bf_bwd_desc = nullptr;
@@ -287,8 +293,53 @@ void build_bwd_stream(const Net& n, int pad_to, std::vector<FragDesc>& out) {
   }
 }
 
+// forward streams of the 16x16x32 inference kernel (mlp_fwd_bf16_t16.hip): a fragment = 16 output rows x one k-step of 32
+// features (FragDesc::transposed == 2), fragments in consumption order (output tile outer, k-step inner; a skip layer's
+// encoding k-steps behind its activation k-steps), every part padded to a whole 32-fragment ring block
+void build_fwd_streams_t16(const Net& n, std::vector<FragDesc>& out_full, std::vector<FragDesc>& out_sigma) {
+  const NetLayout& L = n.L;
+  const int W = L.W, WT = n.WT;
+  const int HT = L.mode == 1 ? std::max(1, WT / 2) : 1;   // colour-hidden tiles of 32 rows (kernel template)
+  auto pad = [](std::vector<FragDesc>& v) {
+    while (v.size() % 32) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 2});
+  };
+  auto ksteps = [&](std::vector<FragDesc>& v, int64_t off, int ld, int row0, int nrows, int col_base, int kfeat, int nks) {
+    for (int ks = 0; ks < nks; ++ks)
+      v.push_back(FragDesc{off, ld, row0, nrows, col_base + 32 * ks, std::max(0, std::min(32, kfeat - 32 * ks)), 0, 2});
+  };
+  auto trunk = [&](std::vector<FragDesc>& v) {
+    for (int l = 0; l < L.D; ++l) {
+      const bool uses_act = l > 0;
+      const bool uses_enc = l == 0 || ((L.skip_mask >> (l - 1)) & 1u);
+      for (int ot = 0; ot < 2 * WT; ++ot) {
+        if (uses_act) ksteps(v, L.w_off[l], L.fan_in[l], 16 * ot, W, 0, W, WT);
+        if (uses_enc) ksteps(v, L.w_off[l], L.fan_in[l], 16 * ot, W, uses_act ? W : 0, L.E, 2);   // 64 padded encoding rows
+      }
+      pad(v);
+    }
+  };
+  out_full.clear(); out_sigma.clear();
+  trunk(out_full);
+  for (int ot = 0; ot < 2 * HT; ++ot) ksteps(out_full, L.wf_off, W, 16 * ot, L.head_rows, 0, W, WT);
+  ksteps(out_full, L.ws_off, W, 0, 1, 0, W, WT);   // density tile: row 0
+  pad(out_full);
+  if (L.mode == 1) {
+    ksteps(out_full, L.wc_off, L.H2, 0, 3, 0, L.H2, HT);
+    pad(out_full);
+  }
+  trunk(out_sigma);
+  ksteps(out_sigma, L.ws_off, W, 0, 1, 0, W, WT);
+  pad(out_sigma);
+}
+
+// Inference forward of the bf16 path: 1 = mlp_fwd_bf16_t16.hip (v_mfma_f32_16x16x32_bf16), 0 = the 32x32x16 kernel the
+// training forward also uses (mlp_fwd_bf16.hip).  Same-box A/B in round 3: see DESIGN.md section 5.
+#ifndef NH_BF_INFER_T16
+#define NH_BF_INFER_T16 1
+#endif
 void build_bf16_streams(Net& n) {
   build_fwd_streams(n, 32, n.bf_full, n.bf_sigma);
+  build_fwd_streams_t16(n, n.bf_full16, n.bf_sigma16);
   build_bwd_stream(n, 32, n.bf_bwd);
 }
 
@@ -362,6 +413,8 @@ int repack(nerfhip* h) {
       };
       seg(n.d_bf_full_desc, n.d_bf_full, n.bf_full.size());
       seg(n.d_bf_sigma_desc, n.d_bf_sigma, n.bf_sigma.size());
+      seg(n.d_bf_full16_desc, n.d_bf_full16, n.bf_full16.size());
+      seg(n.d_bf_sigma16_desc, n.d_bf_sigma16, n.bf_sigma16.size());
       seg(n.d_bf_bwd_desc, n.d_bf_bwd, n.bf_bwd.size());
       a.vparams[i] = p; a.bv[i] = n.d_bvec; a.L[i] = n.L; a.HT[i] = n.L.mode == 1 ? std::max(1, n.WT / 2) : 1;
     }
@@ -412,6 +465,11 @@ int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const floa
   } else if (h->cfg.dtype == NERFHIP_BF16) {
     BfStore bst = n.bst;
     bst.Mpad = (nr * S + 255) / 256 * 256;
+    if (NH_BF_INFER_T16 && !train_store)   // inference: the 16x16x32 kernel on its own fragment order
+      HIPCHK(h, launch_mlp_fwd_bf16_t16(net_args(h, n), want_rgb ? n.d_bf_full16 : n.d_bf_sigma16, n.d_bvec, o, d, z, n.d_dirfeat,
+                                        nr * S, S, sigma, craw, want_rgb ? 1 : 0,
+                                        (int)((want_rgb ? n.bf_full16.size() : n.bf_sigma16.size()) / 32), h->n_cu, h->stream));
+    else
     HIPCHK(h, launch_mlp_fwd_bf16(train_store ? &bst : nullptr, net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z, n.d_dirfeat,
                                   nr * S, S, sigma, craw, want_rgb ? 1 : 0,
                                   (int)((want_rgb ? n.bf_full.size() : n.bf_sigma.size()) / 32), h->n_cu, h->stream));
@@ -638,6 +696,7 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
   if (c.dtype == NERFHIP_BF16) {
     CCHK(prepare_wgrad_bf16());
     CCHK(prepare_mlp_fwd_bf16(c.W, L.mode));
+    CCHK(prepare_mlp_fwd_bf16_t16(c.W, L.mode));
     CCHK(prepare_mlp_bwd_bf16(c.W, L.mode));
   }
   if (c.dtype == NERFHIP_F16X3) { CCHK(prepare_mlp_fwd_f16x3(c.W, L.mode)); CCHK(prepare_mlp_bwd_f16x3(c.W, L.mode)); }
@@ -687,6 +746,14 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
       CCHK(hipMalloc(&n.d_bf_sigma, (n.bf_sigma.size() + padf) * 1024));
       CCHK(hipMemsetAsync(n.d_bf_full, 0, (n.bf_full.size() + padf) * 1024, h->stream));
       CCHK(hipMemsetAsync(n.d_bf_sigma, 0, (n.bf_sigma.size() + padf) * 1024, h->stream));
+      CCHK(dalloc(&n.d_bf_full16_desc, n.bf_full16.size()));
+      CCHK(dalloc(&n.d_bf_sigma16_desc, n.bf_sigma16.size()));
+      CCHK(hipMemcpy(n.d_bf_full16_desc, n.bf_full16.data(), n.bf_full16.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMemcpy(n.d_bf_sigma16_desc, n.bf_sigma16.data(), n.bf_sigma16.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMalloc(&n.d_bf_full16, (n.bf_full16.size() + padf) * 1024));
+      CCHK(hipMalloc(&n.d_bf_sigma16, (n.bf_sigma16.size() + padf) * 1024));
+      CCHK(hipMemsetAsync(n.d_bf_full16, 0, (n.bf_full16.size() + padf) * 1024, h->stream));
+      CCHK(hipMemsetAsync(n.d_bf_sigma16, 0, (n.bf_sigma16.size() + padf) * 1024, h->stream));
       CCHK(dalloc(&n.d_bvec, (size_t)L.D * L.W + 5 * 32 + 32));
       CCHK(dalloc(&n.d_bf_bwd_desc, n.bf_bwd.size()));
       CCHK(hipMemcpy(n.d_bf_bwd_desc, n.bf_bwd.data(), n.bf_bwd.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
@@ -743,7 +810,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems); fr(h->d_amax); fr(h->d_x3flags);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
-    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_bwd_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.d_x3_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
+    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bf_full16_desc); fr(n.d_bf_sigma16_desc); fr(n.d_bf_full16); fr(n.d_bf_sigma16); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_bwd_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.d_x3_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
     fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
     fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.st.mask); fr(n.d_dsigma); fr(n.d_dcraw);
   }

@@ -49,7 +49,8 @@ struct FragDesc {
   int32_t col0;        // canonical column of feature 0 of the 32-feature k-tile
   int32_t kvalid;      // features of the k-tile that exist (the rest read as zero)
   int32_t s;           // k-step inside the k-tile (0 | 1)
-  int32_t transposed;  // 1: element (row, col) = src[col*ld + row]
+  int32_t transposed;  // 1: element (row, col) = src[col*ld + row];  2: not transposed, 16 rows x 32 k-values in the lane order of
+                       // the 16x16x32 MFMA's A operand (mlp_fwd_bf16_t16.hip; s unused)
 };
 
 // Kernel-side description of one network (passed by value).

@@ -49,7 +49,7 @@ hipError_t launch_mlp_bwd_f32(const NetArgs& net, const float* d_sigma, const fl
 hipError_t launch_pack_bvec(const float* params, const NetLayout& L, int HT, float* bv, float scale, hipStream_t s);
 // all bf16 streams and vectors of up to two networks in one launch (pack.hip: repack_bf16_kernel)
 struct RepackBf16Args {
-  static constexpr int kMaxSeg = 6, kBvecBlocks = 16;
+  static constexpr int kMaxSeg = 10, kBvecBlocks = 16;
   struct Seg { const FragDesc* descs; void* dst; const float* params; int32_t first, n; } seg[kMaxSeg];
   int32_t nseg, nfrag, nnets;
   int32_t HT[2];
@@ -71,6 +71,11 @@ hipError_t launch_mlp_bwd_bf16(const BfStore& st, const NetArgs& net, const void
 hipError_t prepare_wgrad_f32();
 hipError_t prepare_wgrad_bf16();
 hipError_t prepare_mlp_fwd_bf16(int W, int mode);
+// inference forward on v_mfma_f32_16x16x32_bf16 (mlp_fwd_bf16_t16.hip); stream_w in FragDesc::transposed == 2 order
+hipError_t prepare_mlp_fwd_bf16_t16(int W, int mode);
+hipError_t launch_mlp_fwd_bf16_t16(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+                                   const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
+                                   float* craw, int want_rgb, int nblk, int n_cu, hipStream_t stream);
 hipError_t prepare_mlp_bwd_bf16(int W, int mode);
 // split-f16 render path (mlp_fwd_f16x3.hip, pack.hip)
 hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, int n, void* dst, uint32_t* flag, hipStream_t s);

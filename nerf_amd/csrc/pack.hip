@@ -30,9 +30,22 @@ __global__ void pack_chunks_kernel(const float* __restrict__ params, const Chunk
 // bf16 weight streams: one block (64 lanes) per fragment; lane (h, i) writes 8 bf16 = W[row0+i][col0 + F(s,h,e)]
 __device__ __forceinline__ void pack_frag_bf16(const float* __restrict__ params, const FragDesc& d, __bf16* __restrict__ dst,
                                                int frag, int lane) {
-  const int h = lane >> 5, i = lane & 31;
   const float* src = params + (d.src_off < 0 ? 0 : d.src_off);
   __bf16* o = dst + ((int64_t)frag * 64 + lane) * 8;
+  if (d.transposed == 2) {
+    // A operand of v_mfma_f32_16x16x32_bf16 (mlp_fwd_bf16_t16.hip): 16 rows x the 32 features of the k-tile, lane (c, g)
+    // holds row row0 + c, k-slots 8 g .. 8 g + 7 = features 16 (e >> 2) + 4 g + (e & 3)
+    const int g = lane >> 4, row = d.row0 + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = 16 * (e >> 2) + 4 * g + (e & 3);
+      float v = 0.f;
+      if (d.src_off >= 0 && row < d.nrows && f < d.kvalid) v = src[(int64_t)row * d.ld + d.col0 + f];
+      o[e] = (__bf16)v;
+    }
+    return;
+  }
+  const int h = lane >> 5, i = lane & 31;
   const int row = d.row0 + i;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {

@@ -1,15 +1,18 @@
-"""Render-only timing of the full network (400x400 frames): python scripts/bench_render.py [f32|bf16|f16x3] [frames]"""
+"""Render-only timing of the full network (400x400 frames): python scripts/bench_render.py [f32|bf16|f16x3] [frames] [library|-] [NImportance]
+(the optional library path is for development builds; NImportance 256 = the sample counts of BASELINE configs[4])"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import helpers as H
 from nerf_amd import NerfBlock, NerfConfig, _lib
-if len(sys.argv) > 3:   # an experimental build of the library (development timing only)
+if len(sys.argv) > 3 and sys.argv[3] != "-":   # an experimental build of the library (development timing only)
     _lib.LIB_PATH = os.path.abspath(sys.argv[3])
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 c = dict(H.CONFIGS["full"], dtype=dtype)
+if len(sys.argv) > 4:
+    c["NImportance"] = int(sys.argv[4])
 n = 160000
 rn = NerfBlock(NerfConfig.from_dict(dict(c, maxRays=n)))
 rn.init_params(1)
