@@ -60,6 +60,12 @@ struct Net {
   void* d_bf_bwd = nullptr;
   // split-f16 path (cfg.dtype == NERFHIP_F16X3): forward streams of (hi, lo) fragment pairs (f16x3_common.hip.h)
   std::vector<FragDesc> x3_full, x3_sigma, x3_bwd;   // x3_bwd: transposed matrices, for the backward kernel
+  // the two forward pair streams in the fragment order of the 16x16x32 inference kernel (mlp_fwd_f16x3_t16.hip)
+  std::vector<FragDesc> x3_full16, x3_sigma16;
+  FragDesc* d_x3_full16_desc = nullptr;
+  FragDesc* d_x3_sigma16_desc = nullptr;
+  void* d_x3_full16 = nullptr;
+  void* d_x3_sigma16 = nullptr;
   FragDesc* d_x3_full_desc = nullptr;
   FragDesc* d_x3_sigma_desc = nullptr;
   FragDesc* d_x3_bwd_desc = nullptr;
@@ -94,6 +100,7 @@ struct nerfhip {
   uint32_t rng_step = 0, last_rng_step = 0;
   bool grads_ready = false;
   bool packed = false;
+  bool x3_infer_dirty = true;   // dtype f16x3: the inference-order pair streams lag behind the parameters (packed on demand)
   hipStream_t own_stream = nullptr, stream = nullptr;
   float* d_pose_rays = nullptr;   // nerfhip_render_pose_u8: rays_o | rays_d | bounds of one frame
   int64_t pose_rays_cap = 0;
@@ -295,13 +302,13 @@ void build_bwd_stream(const Net& n, int pad_to, std::vector<FragDesc>& out) {
 
 // forward streams of the 16x16x32 inference kernel (mlp_fwd_bf16_t16.hip): a fragment = 16 output rows x one k-step of 32
 // features (FragDesc::transposed == 2), fragments in consumption order (output tile outer, k-step inner; a skip layer's
-// encoding k-steps behind its activation k-steps), every part padded to a whole 32-fragment ring block
-void build_fwd_streams_t16(const Net& n, std::vector<FragDesc>& out_full, std::vector<FragDesc>& out_sigma) {
+// encoding k-steps behind its activation k-steps), every part padded to a whole ring block
+void build_fwd_streams_t16(const Net& n, int pad_to, std::vector<FragDesc>& out_full, std::vector<FragDesc>& out_sigma) {
   const NetLayout& L = n.L;
   const int W = L.W, WT = n.WT;
   const int HT = L.mode == 1 ? std::max(1, WT / 2) : 1;   // colour-hidden tiles of 32 rows (kernel template)
-  auto pad = [](std::vector<FragDesc>& v) {
-    while (v.size() % 32) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 2});
+  auto pad = [pad_to](std::vector<FragDesc>& v) {   // 32 fragments, or 16 (hi, lo) pairs: one ring block
+    while (v.size() % pad_to) v.push_back(FragDesc{-1, 0, 0, 0, 0, 0, 0, 2});
   };
   auto ksteps = [&](std::vector<FragDesc>& v, int64_t off, int ld, int row0, int nrows, int col_base, int kfeat, int nks) {
     for (int ks = 0; ks < nks; ++ks)
@@ -337,9 +344,12 @@ void build_fwd_streams_t16(const Net& n, std::vector<FragDesc>& out_full, std::v
 #ifndef NH_BF_INFER_T16
 #define NH_BF_INFER_T16 1
 #endif
+#ifndef NH_X3_INFER_T16   // the same switch for dtype f16x3 (mlp_fwd_f16x3_t16.hip against mlp_fwd_f16x3.hip)
+#define NH_X3_INFER_T16 1
+#endif
 void build_bf16_streams(Net& n) {
   build_fwd_streams(n, 32, n.bf_full, n.bf_sigma);
-  build_fwd_streams_t16(n, n.bf_full16, n.bf_sigma16);
+  build_fwd_streams_t16(n, 32, n.bf_full16, n.bf_sigma16);
   build_bwd_stream(n, 32, n.bf_bwd);
 }
 
@@ -436,6 +446,7 @@ int repack(nerfhip* h) {
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, nullptr, h->stream));
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_bwd_desc, (int)n.x3_bwd.size(), n.d_x3_bwd, nullptr, h->stream));
       HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, 64.0f, h->stream));
+      h->x3_infer_dirty = true;   // the 16x16x32-ordered streams are packed when an inference pass asks for them
     }
   }
   h->packed = true;
@@ -456,7 +467,20 @@ int dir_features(nerfhip* h, Net& n, const float* viewdir, int64_t nr, bool trai
 int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const float* d, const float* z, int64_t nr, int S,
                 float* sigma, float* craw, bool want_rgb) {
   Scope sc(h, P_MLP_FWD);
-  if (h->cfg.dtype == NERFHIP_F16X3) {   // training forward: the same kernels, filling the fp32 path's activation store
+  if (h->cfg.dtype == NERFHIP_F16X3 && NH_X3_INFER_T16 && !train_store) {   // inference: the 16x16x32 kernel on its own pair order
+    if (h->x3_infer_dirty) {   // a training loop never pays for these two streams
+      for (int i = 0; i < h->nnets; ++i) {
+        Net& q = h->nets[i];
+        const float* p = h->d_params + q.param_off;
+        HIPCHK(h, launch_pack_frags_f16x3(p, q.d_x3_full16_desc, (int)q.x3_full16.size(), q.d_x3_full16, nullptr, h->stream));
+        HIPCHK(h, launch_pack_frags_f16x3(p, q.d_x3_sigma16_desc, (int)q.x3_sigma16.size(), q.d_x3_sigma16, nullptr, h->stream));
+      }
+      h->x3_infer_dirty = false;
+    }
+    HIPCHK(h, launch_mlp_fwd_f16x3_t16(net_args(h, n), want_rgb ? n.d_x3_full16 : n.d_x3_sigma16, n.d_bvec, o, d, z, n.d_dirfeat, nr * S, S,
+                                       sigma, craw, want_rgb ? 1 : 0, (int)((want_rgb ? n.x3_full16.size() : n.x3_sigma16.size()) / 16),
+                                       h->n_cu, h->d_x3flags + 2, h->stream));
+  } else if (h->cfg.dtype == NERFHIP_F16X3) {   // training forward: the 32x32x16 kernels, filling the fp32 path's activation store
     ActStore st = n.st;
     st.Mpad = (nr * S + kTile - 1) / kTile * kTile;
     HIPCHK(h, launch_mlp_fwd_f16x3(net_args(h, n), want_rgb ? n.d_x3_full : n.d_x3_sigma, n.d_bvec, o, d, z, n.d_dirfeat, nr * S, S,
@@ -699,7 +723,7 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
     CCHK(prepare_mlp_fwd_bf16_t16(c.W, L.mode));
     CCHK(prepare_mlp_bwd_bf16(c.W, L.mode));
   }
-  if (c.dtype == NERFHIP_F16X3) { CCHK(prepare_mlp_fwd_f16x3(c.W, L.mode)); CCHK(prepare_mlp_bwd_f16x3(c.W, L.mode)); }
+  if (c.dtype == NERFHIP_F16X3) { CCHK(prepare_mlp_fwd_f16x3(c.W, L.mode)); CCHK(prepare_mlp_fwd_f16x3_t16(c.W, L.mode)); CCHK(prepare_mlp_bwd_f16x3(c.W, L.mode)); }
   CCHK(hipGetSymbolAddress((void**)&h->static_scratch, HIP_SYMBOL(scratch)));   // this device's copy of the array
   CCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
@@ -776,6 +800,15 @@ int nerfhip_create(const nerfhip_config* cfg, nerfhip_t** out) {
       CCHK(hipMalloc(&n.d_x3_sigma, (2 * n.x3_sigma.size() + padf) * 1024));
       CCHK(hipMemsetAsync(n.d_x3_full, 0, (2 * n.x3_full.size() + padf) * 1024, h->stream));
       CCHK(hipMemsetAsync(n.d_x3_sigma, 0, (2 * n.x3_sigma.size() + padf) * 1024, h->stream));
+      build_fwd_streams_t16(n, 16, n.x3_full16, n.x3_sigma16);
+      CCHK(dalloc(&n.d_x3_full16_desc, n.x3_full16.size()));
+      CCHK(dalloc(&n.d_x3_sigma16_desc, n.x3_sigma16.size()));
+      CCHK(hipMemcpy(n.d_x3_full16_desc, n.x3_full16.data(), n.x3_full16.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMemcpy(n.d_x3_sigma16_desc, n.x3_sigma16.data(), n.x3_sigma16.size() * sizeof(FragDesc), hipMemcpyHostToDevice));
+      CCHK(hipMalloc(&n.d_x3_full16, (2 * n.x3_full16.size() + padf) * 1024));
+      CCHK(hipMalloc(&n.d_x3_sigma16, (2 * n.x3_sigma16.size() + padf) * 1024));
+      CCHK(hipMemsetAsync(n.d_x3_full16, 0, (2 * n.x3_full16.size() + padf) * 1024, h->stream));
+      CCHK(hipMemsetAsync(n.d_x3_sigma16, 0, (2 * n.x3_sigma16.size() + padf) * 1024, h->stream));
       CCHK(dalloc(&n.d_bvec, (size_t)L.D * L.W + 5 * 32 + 32));
       if (!h->d_x3flags) {
         CCHK(dalloc(&h->d_x3flags, 4));
@@ -810,7 +843,7 @@ void nerfhip_destroy(nerfhip_t* h) {
   fr(h->d_params); fr(h->d_grads); fr(h->d_m); fr(h->d_v); fr(h->d_loss); fr(h->d_items); fr(h->d_items_first); fr(h->d_bitems); fr(h->d_amax); fr(h->d_x3flags);
   for (int i = 0; i < 2; ++i) {
     Net& n = h->nets[i];
-    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bf_full16_desc); fr(n.d_bf_sigma16_desc); fr(n.d_bf_full16); fr(n.d_bf_sigma16); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_bwd_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.d_x3_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
+    fr(n.d_fwd_desc); fr(n.d_bwd_desc); fr(n.d_off_fwd); fr(n.d_off_bwd); fr(n.d_wpack_fwd); fr(n.d_wpack_bwd); fr(n.d_bf_full_desc); fr(n.d_bf_sigma_desc); fr(n.d_bf_full); fr(n.d_bf_sigma); fr(n.d_bf_full16_desc); fr(n.d_bf_sigma16_desc); fr(n.d_bf_full16); fr(n.d_bf_sigma16); fr(n.d_bvec); fr(n.d_bf_bwd_desc); fr(n.d_bf_bwd); fr(n.d_x3_full_desc); fr(n.d_x3_sigma_desc); fr(n.d_x3_bwd_desc); fr(n.d_x3_full); fr(n.d_x3_sigma); fr(n.d_x3_full16_desc); fr(n.d_x3_sigma16_desc); fr(n.d_x3_full16); fr(n.d_x3_sigma16); fr(n.d_x3_bwd); fr(n.bst.enc); fr(n.bst.act); fr(n.bst.hc); fr(n.bst.dy); fr(n.bst.dh); fr(n.bst.encdir); fr(n.bst.relu);
     fr(n.d_vecpack); fr(n.d_dirfeat); fr(n.d_encdirT); fr(n.d_ddirT);
     fr(n.st.enc); fr(n.st.act); fr(n.st.hc); fr(n.st.dy); fr(n.st.dh); fr(n.st.mask); fr(n.d_dsigma); fr(n.d_dcraw);
   }

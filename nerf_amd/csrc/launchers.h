@@ -80,6 +80,11 @@ hipError_t prepare_mlp_bwd_bf16(int W, int mode);
 // split-f16 render path (mlp_fwd_f16x3.hip, pack.hip)
 hipError_t launch_pack_frags_f16x3(const float* params, const FragDesc* descs, int n, void* dst, uint32_t* flag, hipStream_t s);
 hipError_t prepare_mlp_fwd_f16x3(int W, int mode);
+// inference forward on v_mfma_f32_16x16x32_f16 (mlp_fwd_f16x3_t16.hip); stream_w: pairs in FragDesc::transposed == 2 order
+hipError_t prepare_mlp_fwd_f16x3_t16(int W, int mode);
+hipError_t launch_mlp_fwd_f16x3_t16(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
+                                    const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
+                                    float* craw, int want_rgb, int nblk, int n_cu, uint32_t* nonfinite_flag, hipStream_t stream);
 hipError_t launch_mlp_fwd_f16x3(const NetArgs& net, const void* stream_w, const float* bvec, const float* rays_o,
                                 const float* rays_d, const float* z, const float* dirfeat, int64_t M, int S, float* sigma,
                                 float* craw, int want_rgb, int nblk, int n_cu, const ActStore* st, uint32_t* nonfinite_flag,

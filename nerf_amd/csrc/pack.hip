@@ -68,14 +68,15 @@ __global__ __launch_bounds__(64) void pack_frags_f16x3_kernel(const float* __res
   const float* src = params + (d.src_off < 0 ? 0 : d.src_off);
   _Float16* oh = dst + ((int64_t)(2 * blockIdx.x) * 64 + lane) * 8;
   _Float16* ol = oh + 512;
-  const int row = d.row0 + i;
+  const bool t16 = d.transposed == 2;   // A operand order of the 16x16x32 MFMA (pack_frag_bf16; mlp_fwd_f16x3_t16.hip)
+  const int row = d.row0 + (t16 ? (lane & 15) : i);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int f = 16 * d.s + (e & 3) + 8 * (e >> 2) + 4 * h;
+    const int f = t16 ? 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3) : 16 * d.s + (e & 3) + 8 * (e >> 2) + 4 * h;
     float v = 0.f;
     int64_t at = -1;
     if (d.src_off >= 0 && row < d.nrows && f < d.kvalid) {
-      at = d.transposed ? (int64_t)(d.col0 + f) * d.ld + row : (int64_t)row * d.ld + d.col0 + f;
+      at = d.transposed == 1 ? (int64_t)(d.col0 + f) * d.ld + row : (int64_t)row * d.ld + d.col0 + f;
       v = src[at];
     }
     const float vs = __fmul_rn(v, 64.0f);   // exact

@@ -395,8 +395,18 @@ def test_gradients_other_network_shapes(G, variant, dtype):
     blk = G.make_block(c, dtype=dtype)
     blk.set_params(params)
     o = Oracle(c)
-    fine = blk.evaluate(ro, rd, b, rd)
-    np.testing.assert_allclose(fine, o.forward(params, ro, rd, b, rd, training=False)["rgb_fine"], rtol=0, atol=2e-4)
+    # eval render: 2e-4 against the oracle at the DEVICE's fine depths (test_gradients_full says why); against the oracle at
+    # its own depths an isolated fine sample may sit on the other side of samplePdf's `den < 1e-5` branch (seen here once the
+    # f16x3 inference kernel summed in another order: one ray of 53, 2.8e-4): no depth off by more than a coarse bin, 2e-3
+    fine, _, dbg = blk.forward(ro, rd, b, rd, training=False, debug=True)
+    hier = c["useHierarchical"]
+    at_dev = o.forward(params, ro, rd, b, rd, training=False, rand={"z_fine_in": dbg["z_fine"]} if hier else {})
+    np.testing.assert_allclose(fine, at_dev["rgb_fine"], rtol=0, atol=2e-4)
+    own = o.forward(params, ro, rd, b, rd, training=False)
+    np.testing.assert_allclose(fine, own["rgb_fine"], rtol=0, atol=2e-3)
+    if hier:
+        bin_w = np.diff(own["z_coarse"], axis=1).max(axis=1, keepdims=True)
+        assert (np.abs(dbg["z_fine"] - own["z_fine"]) <= bin_w).all()
     lf, lc = blk.train_backward(ro, rd, b, rd, label)
     gr = blk.get_grads()
     ref = o.train_grads(params, ro, rd, b, rd, label)

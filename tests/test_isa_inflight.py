@@ -1,6 +1,6 @@
 """The fused MLP / wgrad kernels issue loads as inline asm and wait for them with hand-counted s_waitcnt many
 instructions later; the compiler must never touch a register whose load may still be outstanding.
-scripts/check_inflight.py verifies that on the final ISA (hipcc cross-compiles without a GPU).  The ten sources are
+scripts/check_inflight.py verifies that on the final ISA (hipcc cross-compiles without a GPU).  The eleven sources are
 compiled to assembly once, side by side (a minute or two instead of five), then every file is checked on its own."""
 import os
 import shutil
@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 SOURCES = ["mlp_fwd.hip", "mlp_bwd.hip", "wgrad.hip", "mlp_fwd_bf16.hip", "mlp_fwd_bf16_t16.hip", "mlp_bwd_bf16.hip", "wgrad_bf16.hip",
-           "mlp_fwd_f16x3.hip", "mlp_bwd_f16x3.hip", "wgrad_f16x3.hip"]
+           "mlp_fwd_f16x3.hip", "mlp_fwd_f16x3_t16.hip", "mlp_bwd_f16x3.hip", "wgrad_f16x3.hip"]
 
 
 def _compile(src, out_dir):
