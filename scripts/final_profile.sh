@@ -20,3 +20,4 @@ bash scripts/pmc_train.sh f32 ${TAG}_f32
 bash scripts/pmc_train.sh f16x3 ${TAG}_f16x3train
 bash scripts/hbm_prof.sh ${TAG}
 bash scripts/x3_prof.sh f16x3 ${TAG}_f16x3
+bash scripts/ns2_prof.sh ${TAG}_bf16render nerf_amd/libnerfhip.so
