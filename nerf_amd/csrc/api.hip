@@ -422,7 +422,7 @@ int repack(nerfhip* h) {
         a.nfrag += (int32_t)cnt;
       };
       seg(n.d_bf_full_desc, n.d_bf_full, n.bf_full.size());
-      seg(n.d_bf_sigma_desc, n.d_bf_sigma, n.bf_sigma.size());
+      if (!NH_BF_INFER_T16) seg(n.d_bf_sigma_desc, n.d_bf_sigma, n.bf_sigma.size());   // density-only 32x32x16 stream: inference only
       seg(n.d_bf_full16_desc, n.d_bf_full16, n.bf_full16.size());
       seg(n.d_bf_sigma16_desc, n.d_bf_sigma16, n.bf_sigma16.size());
       seg(n.d_bf_bwd_desc, n.d_bf_bwd, n.bf_bwd.size());
@@ -443,7 +443,8 @@ int repack(nerfhip* h) {
     HIPCHK(h, launch_pack_vec(p, n.L, n.HT, n.d_vecpack, h->stream));
     if (h->cfg.dtype == NERFHIP_F16X3) {   // the split-f16 kernels' pair streams (forward, density-only, backward)
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_full_desc, (int)n.x3_full.size(), n.d_x3_full, h->d_x3flags + i, h->stream));
-      HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, nullptr, h->stream));
+      if (!NH_X3_INFER_T16)   // the density-only 32x32x16 stream is read by the old inference kernel only
+        HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_sigma_desc, (int)n.x3_sigma.size(), n.d_x3_sigma, nullptr, h->stream));
       HIPCHK(h, launch_pack_frags_f16x3(p, n.d_x3_bwd_desc, (int)n.x3_bwd.size(), n.d_x3_bwd, nullptr, h->stream));
       HIPCHK(h, launch_pack_bvec(p, n.L, n.L.mode == 1 ? std::max(1, n.WT / 2) : 1, n.d_bvec, 64.0f, h->stream));
       h->x3_infer_dirty = true;   // the 16x16x32-ordered streams are packed when an inference pass asks for them
