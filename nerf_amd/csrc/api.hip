@@ -494,10 +494,10 @@ int mlp_forward(nerfhip* h, Net& n, bool train_store, const float* o, const floa
       HIPCHK(h, launch_mlp_fwd_bf16_t16(net_args(h, n), want_rgb ? n.d_bf_full16 : n.d_bf_sigma16, n.d_bvec, o, d, z, n.d_dirfeat,
                                         nr * S, S, sigma, craw, want_rgb ? 1 : 0,
                                         (int)((want_rgb ? n.bf_full16.size() : n.bf_sigma16.size()) / 32), h->n_cu, h->stream));
-    else
-    HIPCHK(h, launch_mlp_fwd_bf16(train_store ? &bst : nullptr, net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z, n.d_dirfeat,
-                                  nr * S, S, sigma, craw, want_rgb ? 1 : 0,
-                                  (int)((want_rgb ? n.bf_full.size() : n.bf_sigma.size()) / 32), h->n_cu, h->stream));
+    else   // training forward (and, with NH_BF_INFER_T16 = 0, inference): the 32x32x16 kernel
+      HIPCHK(h, launch_mlp_fwd_bf16(train_store ? &bst : nullptr, net_args(h, n), want_rgb ? n.d_bf_full : n.d_bf_sigma, n.d_bvec, o, d, z,
+                                    n.d_dirfeat, nr * S, S, sigma, craw, want_rgb ? 1 : 0,
+                                    (int)((want_rgb ? n.bf_full.size() : n.bf_sigma.size()) / 32), h->n_cu, h->stream));
   } else {
     ActStore st = n.st;
     st.Mpad = (nr * S + kTile - 1) / kTile * kTile;
