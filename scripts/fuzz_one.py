@@ -30,14 +30,18 @@ for dtype in ("f32", "f16x3"):
     tr = o.train_grads(params, ro, rd, b, rd, label, rand=dict(rand, z_fine_in=dbg["z_fine"]))
     gr, rg = blk.get_grads(), tr["grads"]
     print(dtype, "whole", np.linalg.norm(gr - rg) / np.linalg.norm(rg))
+    rows_of = {nm: r for nm, r, _ in H.layout(c)}
     for net, nm, o_, k in H.param_spans(c):
         e = np.linalg.norm(gr[o_:o_ + k] - rg[o_:o_ + k]); nn = np.linalg.norm(rg[o_:o_ + k])
         flag = " <<<" if e > 2e-3 * nn else ""
         print("  ", net, nm, "err %.3e norm %.3e rel %.2e%s" % (e, nn, e / max(nn, 1e-30), flag))
-        if flag and nm.startswith("w"):
-            rows = c["W"] if k % c["W"] == 0 else 1
+        if e > 1e-4 * nn and nm.startswith("w"):
+            rows = rows_of[nm]
             d = (gr[o_:o_ + k] - rg[o_:o_ + k]).reshape(rows, -1)
             rn = np.linalg.norm(d, axis=1)
             top = np.argsort(-rn)[:4]
             print("      rows with most error:", [(int(t), float(rn[t])) for t in top], "all-rows", float(np.linalg.norm(rn)))
+            if rows > 1 and rn[top[0]] > 100 * rn[top[1]]:
+                print("      => ONE unit: network %d, %s row %d carries %.6f of this tensor's error (the next row %.1e of it)"
+                      % (net, nm, top[0], rn[top[0]] / np.linalg.norm(rn), rn[top[1]] / np.linalg.norm(rn)))
     blk.close()
