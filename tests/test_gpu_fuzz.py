@@ -8,7 +8,7 @@ The seeds kept here are green; of 2 500 explored (scripts/fuzz_explore.py, profi
 (355, 715, 1236, 1237, 1460, 1572, 1631, 1644, 1883, 1958, 1972, 1974, 2092, 2476), each by ONE ReLU whose pre-activation is within
 fp32 rounding of zero at one sample (1e-8 ... 7e-7 in magnitude against a median of 0.2-1.6; 355: -4.2e-8), where device and oracle
 legitimately take different sides: one row of one matrix carries that tensor's whole error, the layers above it agree to 1e-7, the
-layers below it move by 0.2-1.7 % of their norms, and in eleven of the fourteen the other device arithmetic (f32 / f16x3) agrees
+layers below it move by 0.2-1.7 % of their norms, and in ten of the fourteen the other device arithmetic (f32 / f16x3) agrees
 with the oracle on the same seed (scripts/fuzz_one.py prints where the error sits and the unit's pre-activations in float64;
 profiles/r3_fuzz_fence_cases.txt)."""
 import numpy as np
