@@ -41,12 +41,29 @@ class LinBf16(torch.autograd.Function):
         return gx, g2.t() @ x2, g2.sum(0).reshape(1, -1), None
 
 
+def position_code_device(x, L):
+    """positionCode as the bf16 kernels evaluate it (csrc/bf16_common.hip.h: code_value_fast): the argument in revolutions,
+    x 2^f fl32(1 / 2 pi) rounded to fp32 -- 6e-8 relative of up to 330 revolutions at f = 9, i.e. up to 1.2e-4 rad -- reduced by
+    fract and handed to the hardware sine (taken as exact here).  An encoding value within that distance of a bf16 rounding
+    boundary lands on the other bf16 value than the exact sine's does."""
+    out = [x]
+    inv2pi = np.float32(0.15915494309189535)
+    for i in range(L):
+        rev = (x * float(np.float32(1 << i) * inv2pi)).to(torch.float32)
+        rev = (rev - torch.floor(rev)).to(torch.float64)
+        out += [torch.sin(2 * np.pi * rev).to(torch.float32), torch.cos(2 * np.pi * rev).to(torch.float32)]
+    return torch.cat(out, -1)
+
+
 def lin(x, w, b, fwd_round=True):
     return LinBf16.apply(x, w, b, fwd_round)
 
 
+_DEVICE_ENCODING = False
+
+
 def core_block_bf16(c, p, pos, dirs, training, is_coarse):
-    enc = mg.position_code(pos, c["posL"])
+    enc = (position_code_device if _DEVICE_ENCODING else mg.position_code)(pos, c["posL"])
     h = enc
     for i in range(c["D"]):
         h = torch.relu(lin(h, p[f"w{i}"], p[f"b{i}"]))
@@ -71,8 +88,12 @@ def core_block_bf16(c, p, pos, dirs, training, is_coarse):
     return d, rgb
 
 
-def train_grads(c, flat, o, d, bounds, label, rand_np=None):
-    """-> (loss_fine, loss_coarse or None, flat gradient) of the bf16-emulated training forward/backward."""
+def train_grads(c, flat, o, d, bounds, label, rand_np=None, z_fine_in=None, device_encoding=False):
+    """-> (loss_fine, loss_coarse or None, flat gradient) of the bf16-emulated training forward/backward.
+    z_fine_in ([rays][N + NImportance], e.g. the device's): the fine pass at THESE depths instead of the emulation's own
+    resampling (the sampler carries no gradient, nerfBlock.scala:81; a coarse weight that differs in its last bits can move a
+    fine sample across a bin, which is the sampler's discontinuity, not the arithmetic under test).
+    device_encoding: the positional encoding of the SAMPLE POSITIONS with the kernels' argument rounding (position_code_device)."""
     rand_np = rand_np or {}
     tflat = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32).copy()).requires_grad_(True)
     nets = H.split_params(c, tflat)
@@ -85,12 +106,18 @@ def train_grads(c, flat, o, d, bounds, label, rand_np=None):
             t = t[..., 0]
         rand[k] = t
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-    saved = mg.core_block
+    global _DEVICE_ENCODING
+    saved, saved_pdf = mg.core_block, mg.sample_pdf
     mg.core_block = core_block_bf16
+    _DEVICE_ENCODING = bool(device_encoding)
+    if z_fine_in is not None and c["useHierarchical"]:
+        zf = torch.from_numpy(np.ascontiguousarray(np.asarray(z_fine_in, np.float32).T)).unsqueeze(-1)   # [sample][ray][1]
+        mg.sample_pdf = lambda c_, w, z, o_, d_, u: (o_ + d_ * zf, zf, None, None, None)
     try:
         out = mg.forward(c, nets, to(o), to(d), to(bounds), to(d), True, rand)
     finally:
-        mg.core_block = saved
+        mg.core_block, mg.sample_pdf = saved, saved_pdf
+        _DEVICE_ENCODING = False
     lab = to(label)
     lf = ((lab - out["rgb_fine"]) ** 2).mean()
     loss, lc = lf, None

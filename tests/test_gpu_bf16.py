@@ -137,6 +137,47 @@ def test_gradients_bf16(G, case):
     blk.close()
 
 
+@pytest.mark.parametrize("seed", [66, 415, 445, 951, "full"])
+def test_gradients_bf16_with_the_kernels_encoding_argument(G, seed):
+    """Where the 2e-2 of test_gradients_bf16 comes from.  Over 1 181 random configurations (scripts/fuzz_bf16_grads.py,
+    profiles/r3_fuzz_bf16_grads*.txt) the distance between the bf16 kernels and their emulation doubles with every encoding
+    frequency (median 5e-5 at posL = 0, 3.6e-3 at posL = 10; 13 configurations with posL >= 8 over the 2e-2) -- because the
+    emulation takes sin(x 2^f) exactly while the kernels reduce x 2^f fl32(1 / 2 pi) rounded to fp32 (up to 1.2e-4 rad off at
+    f = 9), so ~4 % of the top-frequency encodings land on the neighbouring bf16 value.  With that one rounding modelled
+    (bf16_ref.position_code_device) and the fine pass at the device's depths the dependence on posL is gone: median 1.2e-4,
+    99 % within 3.9e-3, none of the 1 181 over the bars.  Here: four of the 13 (posL = 10, kernels against the emulation
+    2.2e-2 ... 6.0e-2 with the exact sine) and BASELINE's full network -- whole gradient within 5e-3 of the emulation with the
+    kernels' argument, and at least 5 x closer to it than to the exact-sine emulation."""
+    import bf16_ref
+    if seed == "full":
+        c = H.CONFIGS["full"]
+        n = 24
+        ro, rd, b, label = H.make_rays(n, 77)
+        params = H.make_params(c, 9)
+    else:
+        import test_gpu_fuzz as F
+        c, n, _ = F.draw(seed)
+        ro, rd, b, label = H.make_rays(n, 200 + seed)
+        params = H.make_params(c, 50 + seed)
+    c = dict(c, perturb=False, rawNoiseStd=0.0)
+    blk = G.make_block(c, max_rays=max(n, 8), dtype="bf16")
+    blk.set_params(params)
+    lf, lc, dbg = blk.train_backward(ro, rd, b, rd, label, debug=True)
+    gr = blk.get_grads()
+    blk.close()
+    zf = dbg["z_fine"] if c["useHierarchical"] else None
+    err = {}
+    for dev in (False, True):
+        rlf, rlc, rg = bf16_ref.train_grads(c, params, ro, rd, b, label, None, z_fine_in=zf, device_encoding=dev)
+        err[dev] = np.linalg.norm(gr - rg) / np.linalg.norm(rg)
+        if dev:
+            assert lf == pytest.approx(rlf, rel=1e-3)
+    assert err[True] < 5e-3, err
+    assert err[True] < 0.2 * err[False], err      # full network, 24 rays: 1.0e-3 against 3.5e-2
+    if seed != "full":
+        assert err[False] > 2e-2, err
+
+
 @pytest.mark.parametrize("variant", ["w128_dir", "w128_nodir_odd", "w256_shallow_sh", "d1_flat"])
 def test_bf16_other_network_shapes(G, variant):
     """Network shapes the golden cases do not reach (W = 128 -> 4 tiles, odd layer counts, D = 1, a skip right before
